@@ -1,0 +1,300 @@
+# coding=utf-8
+"""
+ctypes binding of ``libdeconv3d_hip.so`` (C ABI: include/deconv3d_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing, or no HIP
+device is visible when an :class:`Engine` is created, this raises.  The CPU
+oracle under ``oracle/`` is test infrastructure and is never imported here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdeconv3d_hip.so")
+
+# every symbol include/deconv3d_hip.h declares (tests check the export list)
+SYMBOLS = [
+    "d3d_version", "d3d_last_error", "d3d_device_count",
+    "d3d_ctx_create", "d3d_ctx_destroy", "d3d_ctx_set_stream", "d3d_sync",
+    "d3d_timer_start", "d3d_timer_stop",
+    "d3d_set_taps", "d3d_set_data", "d3d_set_params", "d3d_get_params",
+    "d3d_build_clean", "d3d_convolve", "d3d_forward", "d3d_residual",
+    "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
+    "d3d_convolve_slots", "d3d_mh_config", "d3d_window_stats",
+    "d3d_mh_sweeps", "d3d_get_dlog", "d3d_colour_count",
+]
+
+SLOT_DATA, SLOT_IVAR, SLOT_ERR, SLOT_SIM, SLOT_TMP0, SLOT_TMP1 = range(6)
+
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = -1, -2, -3, -4, -5
+
+
+class HipLibraryMissing(ImportError):
+    """libdeconv3d_hip.so has not been built (run __graft_entry__.build())."""
+
+
+class HipError(RuntimeError):
+    """A HIP runtime call failed, or no HIP device is available."""
+
+
+_lib = None
+
+
+def _dp(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def load():
+    """Load the shared library (once) and declare the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). deconv3d_amd has no CPU "
+            "fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    ctx_p = C.c_void_p
+    dbl_p = C.POINTER(C.c_double)
+    lib.d3d_version.restype = C.c_int
+    lib.d3d_last_error.restype = C.c_char_p
+    lib.d3d_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.d3d_ctx_create.argtypes = [C.POINTER(ctx_p)] + [C.c_int] * 6
+    lib.d3d_ctx_destroy.argtypes = [ctx_p]
+    lib.d3d_ctx_set_stream.argtypes = [ctx_p, C.c_void_p]
+    lib.d3d_sync.argtypes = [ctx_p]
+    lib.d3d_timer_start.argtypes = [ctx_p]
+    lib.d3d_timer_stop.argtypes = [ctx_p, dbl_p]
+    lib.d3d_set_taps.argtypes = [ctx_p, dbl_p, dbl_p, C.c_double]
+    lib.d3d_set_data.argtypes = [ctx_p, dbl_p, dbl_p, C.c_double,
+                                 C.POINTER(C.c_uint8)]
+    lib.d3d_set_params.argtypes = [ctx_p, dbl_p]
+    lib.d3d_get_params.argtypes = [ctx_p, dbl_p]
+    lib.d3d_build_clean.argtypes = [ctx_p, dbl_p]
+    lib.d3d_convolve.argtypes = [ctx_p, dbl_p, dbl_p]
+    lib.d3d_forward.argtypes = [ctx_p, dbl_p]
+    lib.d3d_residual.argtypes = [ctx_p, dbl_p]
+    lib.d3d_chi2_map.argtypes = [ctx_p, dbl_p, dbl_p]
+    lib.d3d_upload_slot.argtypes = [ctx_p, C.c_int, dbl_p]
+    lib.d3d_download_slot.argtypes = [ctx_p, C.c_int, dbl_p]
+    lib.d3d_convolve_slots.argtypes = [ctx_p, C.c_int, C.c_int]
+    lib.d3d_mh_config.argtypes = [ctx_p, dbl_p, dbl_p, dbl_p, C.c_double,
+                                  C.c_uint64, C.c_int]
+    lib.d3d_window_stats.argtypes = [ctx_p, C.c_int, C.c_int, dbl_p, dbl_p]
+    lib.d3d_mh_sweeps.argtypes = [ctx_p, C.c_int, C.c_int, C.c_int, dbl_p,
+                                  dbl_p, C.POINTER(C.c_int64)]
+    lib.d3d_get_dlog.argtypes = [ctx_p, dbl_p]
+    lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("d3d_version", "d3d_last_error"):
+            fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def device_count():
+    lib = load()
+    n = C.c_int(0)
+    lib.d3d_device_count(C.byref(n))
+    return n.value
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = load().d3d_last_error().decode("utf-8", "replace")
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_STATE:
+        raise RuntimeError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipError(msg)
+
+
+def _c64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("expected shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+class Engine(object):
+    """
+    One device context: cube shape ``(D, H, W)``, FSF shape ``(fh, fw)``.
+    Thin, typed mirror of the C ABI; arrays in the reference's layouts.
+    """
+
+    def __init__(self, shape, fsf_shape, device=0):
+        self._lib = load()
+        self._ctx = C.c_void_p(None)
+        D, H, W = [int(v) for v in shape]
+        fh, fw = [int(v) for v in fsf_shape]
+        self.shape = (D, H, W)
+        self.fsf_shape = (fh, fw)
+        _check(self._lib.d3d_ctx_create(C.byref(self._ctx), int(device),
+                                        D, H, W, fh, fw))
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.d3d_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- plumbing ---------------------------------------------------------
+    def set_stream(self, stream_handle):
+        _check(self._lib.d3d_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)))
+
+    def sync(self):
+        _check(self._lib.d3d_sync(self._ctx))
+
+    def timer_start(self):
+        _check(self._lib.d3d_timer_start(self._ctx))
+
+    def timer_stop(self):
+        ms = C.c_double(0.)
+        _check(self._lib.d3d_timer_stop(self._ctx, C.byref(ms)))
+        return ms.value
+
+    # -- inputs -----------------------------------------------------------
+    def set_taps(self, fsf, lsf, lsf_rel_threshold=1e-20):
+        fsf = _c64(fsf, self.fsf_shape)
+        lsf_p = None
+        if lsf is not None:
+            lsf = _c64(lsf, (self.shape[0],))
+            lsf_p = _dp(lsf)
+        _check(self._lib.d3d_set_taps(self._ctx, _dp(fsf), lsf_p,
+                                      float(lsf_rel_threshold)))
+
+    def set_data(self, data, var=None, var_scalar=1.0, mask=None):
+        data = _c64(data, self.shape)
+        var_p = None
+        if var is not None:
+            var = _c64(var, self.shape)
+            var_p = _dp(var)
+        mask_p = None
+        if mask is not None:
+            mask = np.ascontiguousarray(np.asarray(mask) == 1, dtype=np.uint8)
+            if mask.shape != self.shape[1:]:
+                raise ValueError("mask shape %s != %s" % (mask.shape, self.shape[1:]))
+            mask_p = mask.ctypes.data_as(C.POINTER(C.c_uint8))
+        _check(self._lib.d3d_set_data(self._ctx, _dp(data), var_p,
+                                      float(var_scalar), mask_p))
+
+    def set_params(self, params):
+        params = _c64(params, self.shape[1:] + (3,))
+        _check(self._lib.d3d_set_params(self._ctx, _dp(params)))
+
+    def get_params(self):
+        out = np.empty(self.shape[1:] + (3,), dtype=np.float64)
+        _check(self._lib.d3d_get_params(self._ctx, _dp(out)))
+        return out
+
+    # -- forward model ----------------------------------------------------
+    def build_clean(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(self._lib.d3d_build_clean(self._ctx, _dp(out)))
+        return out
+
+    def convolve(self, cube):
+        cube = _c64(cube, self.shape)
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(self._lib.d3d_convolve(self._ctx, _dp(cube), _dp(out)))
+        return out
+
+    def forward(self, fetch=True):
+        out = np.empty(self.shape, dtype=np.float64) if fetch else None
+        _check(self._lib.d3d_forward(self._ctx, _dp(out) if fetch else None))
+        return out
+
+    def residual(self, fetch=True):
+        out = np.empty(self.shape, dtype=np.float64) if fetch else None
+        _check(self._lib.d3d_residual(self._ctx, _dp(out) if fetch else None))
+        return out
+
+    def chi2_map(self):
+        out = np.empty(self.shape[1:], dtype=np.float64)
+        tot = C.c_double(0.)
+        _check(self._lib.d3d_chi2_map(self._ctx, _dp(out), C.byref(tot)))
+        return out, tot.value
+
+    def upload_slot(self, slot, cube):
+        cube = _c64(cube, self.shape)
+        _check(self._lib.d3d_upload_slot(self._ctx, int(slot), _dp(cube)))
+
+    def download_slot(self, slot):
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(self._lib.d3d_download_slot(self._ctx, int(slot), _dp(out)))
+        return out
+
+    def convolve_slots(self, src, dst):
+        _check(self._lib.d3d_convolve_slots(self._ctx, int(src), int(dst)))
+
+    # -- MH within Gibbs --------------------------------------------------
+    def mh_config(self, min_b, max_b, jump_amp, gibbs_apriori_variance, seed=12345,
+                  refresh_every=1000):
+        mn = _c64(min_b, (3,))
+        mx = _c64(max_b, (3,))
+        amp = _c64(np.ones(3) * np.asarray(jump_amp, dtype=np.float64), (3,))
+        _check(self._lib.d3d_mh_config(self._ctx, _dp(mn), _dp(mx), _dp(amp),
+                                       float(gibbs_apriori_variance),
+                                       C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                       int(refresh_every)))
+
+    def window_stats(self, y, x, p_new):
+        p = _c64(p_new, (3,))
+        out = np.empty(5, dtype=np.float64)
+        _check(self._lib.d3d_window_stats(self._ctx, int(y), int(x), _dp(p), _dp(out)))
+        return out
+
+    def mh_sweeps(self, n_sweeps, first_sweep, keep_one_in=1, chain=None, dlog=None):
+        """Returns the number of accepted MH proposals."""
+        H, W = self.shape[1:]
+        chain_p = None
+        dlog_p = None
+        last = (first_sweep + n_sweeps - 1) // keep_one_in
+        if chain is not None:
+            if (chain.dtype != np.float64 or not chain.flags.c_contiguous
+                    or chain.shape[1:] != (H, W, 3) or chain.shape[0] <= last):
+                raise ValueError("chain must be C-contiguous float64 (n>%d,%d,%d,3)"
+                                 % (last, H, W))
+            chain_p = _dp(chain)
+        if dlog is not None:
+            if (dlog.dtype != np.float64 or not dlog.flags.c_contiguous
+                    or dlog.shape[1:] != (H, W) or dlog.shape[0] <= last):
+                raise ValueError("dlog must be C-contiguous float64 (n>%d,%d,%d)"
+                                 % (last, H, W))
+            dlog_p = _dp(dlog)
+        acc = C.c_int64(0)
+        _check(self._lib.d3d_mh_sweeps(self._ctx, int(n_sweeps), int(first_sweep),
+                                       int(keep_one_in), chain_p, dlog_p,
+                                       C.byref(acc)))
+        return acc.value
+
+    def get_dlog(self):
+        out = np.empty(self.shape[1:], dtype=np.float64)
+        _check(self._lib.d3d_get_dlog(self._ctx, _dp(out)))
+        return out
+
+    def colour_count(self, colour):
+        n = C.c_int(0)
+        _check(self._lib.d3d_colour_count(self._ctx, int(colour), C.byref(n)))
+        return n.value

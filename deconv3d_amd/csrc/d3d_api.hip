@@ -1,0 +1,816 @@
+// C ABI of libdeconv3d_hip.so -- see include/deconv3d_hip.h.
+// Host-side context, device memory, launch geometry.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/deconv3d_hip.h"
+#include "d3d_kernels.h"
+
+#define D3D_VERSION 100  // 0.1.0
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(D3D_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+#define NEED(cond, code, ...) \
+    do {                      \
+        if (!(cond)) return fail(code, __VA_ARGS__); \
+    } while (0)
+
+int next_pow2_ref(int depth) {
+    // lib/convolution.py:137-141: 2 ** len(bin(depth-1)[:-1] + '0')
+    unsigned v = (unsigned)(depth - 1);
+    int bits = 0;
+    do {
+        ++bits;
+        v >>= 1;
+    } while (v);
+    return 1 << bits;
+}
+
+}  // namespace
+
+struct d3d_ctx {
+    int device = 0;
+    int D = 0, H = 0, W = 0, fh = 0, fw = 0;
+    int Dp = 0, HL = 0, N = 0;
+    long HW = 0;
+    size_t cube_elems = 0;  // HW * Dp
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    double *slot[D3D_SLOT_COUNT] = {};
+    double *stage = nullptr;   // D*HW doubles, host-layout staging
+    double *stage2 = nullptr;  // second staging (variance)
+    double *params = nullptr;  // HW*3
+    uint8_t *mask = nullptr;   // HW
+    double *fsf = nullptr;     // fh*fw
+    int *lsf_shift = nullptr;
+    double *lsf_weight = nullptr;
+    int ntaps = 0;
+    double *dlog = nullptr;  // HW
+    double *hwbuf = nullptr; // HW scratch (chi2 map)
+    double *scal = nullptr;  // small device scalars (8 doubles)
+    unsigned long long *accepted = nullptr;
+    int *spx = nullptr;  // spaxel lists per colour, concatenated
+    std::vector<int> colour_off;  // fh*fw + 1
+    std::vector<uint8_t> h_mask;
+
+    bool have_taps = false, have_data = false, have_params = false, have_cfg = false;
+    bool err_valid = false;
+    double min_b[3] = {}, max_b[3] = {}, amp[3] = {};
+    double ra = 0;
+    uint64_t seed = 0;
+    int refresh_every = 1000;
+
+    int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
+    int sp_nt = 256;              // spectral / spatial block size
+};
+
+namespace {
+
+using namespace d3d;
+
+d3d::SpectralArgs spectral_args(const d3d_ctx *c) {
+    d3d::SpectralArgs A;
+    A.D = c->D;
+    A.Dp = c->Dp;
+    A.HL = c->HL;
+    A.N = c->N;
+    A.ntaps = c->ntaps;
+    A.nspax = c->HW;
+    A.shift = c->lsf_shift;
+    A.weight = c->lsf_weight;
+    return A;
+}
+
+// block size for the group-per-spaxel kernels: at least HL threads.
+int pick_nt(int HL) {
+    if (HL <= 256) return 256;
+    if (HL <= 512) return 512;
+    return 1024;
+}
+
+int to_device_layout(d3d_ctx *c, const double *src_stage, double *dst) {
+    dim3 grid((unsigned)((c->HW + 31) / 32), (unsigned)((c->Dp + 31) / 32));
+    hipLaunchKernelGGL(d3d::k_to_device_layout, grid, dim3(256), 0, c->stream, src_stage, dst, c->D,
+                       c->Dp, c->HW);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int to_host_layout(d3d_ctx *c, const double *src, double *dst_stage) {
+    dim3 grid((unsigned)((c->HW + 31) / 32), (unsigned)((c->Dp + 31) / 32));
+    hipLaunchKernelGGL(d3d::k_to_host_layout, grid, dim3(256), 0, c->stream, src, dst_stage, c->D,
+                       c->Dp, c->HW);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int upload_cube(d3d_ctx *c, const double *host, double *dst) {
+    const size_t bytes = (size_t)c->D * c->HW * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(c->stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return to_device_layout(c, c->stage, dst);
+}
+
+int download_cube(d3d_ctx *c, const double *src, double *host) {
+    const size_t bytes = (size_t)c->D * c->HW * sizeof(double);
+    int rc = to_host_layout(c, src, c->stage);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+template <int NT>
+int launch_lines_nt(d3d_ctx *c, double *out, int convolved) {
+    d3d::SpectralArgs A = spectral_args(c);
+    const int G = NT / c->HL;
+    const unsigned grid = (unsigned)((c->HW + G - 1) / G);
+    const size_t lds = (size_t)G * c->N * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_lines<NT>), dim3(grid), dim3(NT), lds, c->stream, A,
+                       c->params, c->mask, out, convolved);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_lines(d3d_ctx *c, double *out, int convolved) {
+    switch (pick_nt(c->HL)) {
+        case 256: return launch_lines_nt<256>(c, out, convolved);
+        case 512: return launch_lines_nt<512>(c, out, convolved);
+        default: return launch_lines_nt<1024>(c, out, convolved);
+    }
+}
+
+template <int NT>
+int launch_spectral_nt(d3d_ctx *c, const double *in, double *out) {
+    d3d::SpectralArgs A = spectral_args(c);
+    const int G = NT / c->HL;
+    const unsigned grid = (unsigned)((c->HW + G - 1) / G);
+    const size_t lds = (size_t)G * c->N * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral<NT>), dim3(grid), dim3(NT), lds, c->stream,
+                       A, in, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_spectral(d3d_ctx *c, const double *in, double *out) {
+    switch (pick_nt(c->HL)) {
+        case 256: return launch_spectral_nt<256>(c, in, out);
+        case 512: return launch_spectral_nt<512>(c, in, out);
+        default: return launch_spectral_nt<1024>(c, in, out);
+    }
+}
+
+template <int NT, int FW>
+int launch_spatial_fw(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    constexpr int TX = 8;
+    const int S = NT / c->HL;
+    const long strips = (long)c->H * ((c->W + TX - 1) / TX);
+    const unsigned grid = (unsigned)((strips + S - 1) / S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial<NT, FW, TX>), dim3(grid), dim3(NT), 0,
+                       c->stream, A, in, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NT>
+int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *data) {
+    d3d::SpatialArgs A;
+    A.Dp = c->Dp;
+    A.HL = c->HL;
+    A.H = c->H;
+    A.W = c->W;
+    A.fh = c->fh;
+    A.fw = c->fw;
+    A.fsf = c->fsf;
+    A.data = data;
+    switch (c->fw) {
+        case 1: return launch_spatial_fw<NT, 1>(c, A, in, out);
+        case 3: return launch_spatial_fw<NT, 3>(c, A, in, out);
+        case 5: return launch_spatial_fw<NT, 5>(c, A, in, out);
+        case 7: return launch_spatial_fw<NT, 7>(c, A, in, out);
+        case 9: return launch_spatial_fw<NT, 9>(c, A, in, out);
+        case 11: return launch_spatial_fw<NT, 11>(c, A, in, out);
+        case 13: return launch_spatial_fw<NT, 13>(c, A, in, out);
+        case 15: return launch_spatial_fw<NT, 15>(c, A, in, out);
+        default: break;
+    }
+    const int S = NT / c->HL;
+    const unsigned grid = (unsigned)((c->HW + S - 1) / S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_generic<NT>), dim3(grid), dim3(NT), 0,
+                       c->stream, A, in, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// out = FSF (*) in, or data - FSF (*) in when data != NULL.  in != out.
+int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data) {
+    switch (pick_nt(c->HL)) {
+        case 256: return launch_spatial_nt<256>(c, in, out, data);
+        case 512: return launch_spatial_nt<512>(c, in, out, data);
+        default: return launch_spatial_nt<1024>(c, in, out, data);
+    }
+}
+
+// params -> SLOT_TMP0 (LSF lines) -> dst (sim, or residual when resid)
+int forward_into(d3d_ctx *c, double *dst, bool resid) {
+    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 1);
+    if (rc) return rc;
+    return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, resid ? c->slot[D3D_SLOT_DATA] : nullptr);
+}
+
+void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
+    P.D = c->D;
+    P.Dp = c->Dp;
+    P.HL = c->HL;
+    P.H = c->H;
+    P.W = c->W;
+    P.fh = c->fh;
+    P.fw = c->fw;
+    P.N = c->N;
+    P.ntaps = c->ntaps;
+    P.npos = c->fh * c->fw;
+    P.err = c->slot[D3D_SLOT_ERR];
+    P.ivar = c->slot[D3D_SLOT_IVAR];
+    P.params = c->params;
+    P.fsf = c->fsf;
+    P.shift = c->lsf_shift;
+    P.weight = c->lsf_weight;
+    P.dlog = c->dlog;
+    P.accepted = c->accepted;
+    P.spx = c->spx;
+    for (int k = 0; k < 3; ++k) {
+        P.min_b[k] = c->min_b[k];
+        P.max_b[k] = c->max_b[k];
+        P.amp[k] = c->amp[k];
+    }
+    P.ra = c->ra;
+    P.seed = c->seed;
+    P.probe = 0;
+    P.probe_sp = 0;
+    P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
+    P.probe_out = c->scal;
+}
+
+template <int NT, int MAXIT>
+int launch_mh_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh<NT, MAXIT>), dim3(grid), dim3(NT), lds, c->stream,
+                       P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NT>
+int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    switch (c->mh_maxit) {
+        case 4: return launch_mh_t<NT, 4>(c, P, grid, sweep);
+        case 8: return launch_mh_t<NT, 8>(c, P, grid, sweep);
+        case 16: return launch_mh_t<NT, 16>(c, P, grid, sweep);
+        case 32: return launch_mh_t<NT, 32>(c, P, grid, sweep);
+        default: return launch_mh_t<NT, 0>(c, P, grid, sweep);
+    }
+}
+
+int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    switch (c->mh_nt) {
+        case 256: return launch_mh_nt<256>(c, P, grid, sweep);
+        case 512: return launch_mh_nt<512>(c, P, grid, sweep);
+        default: return launch_mh_nt<1024>(c, P, grid, sweep);
+    }
+}
+
+// Choose the MH workgroup: NT threads, window kept in MAXIT double2 registers
+// per thread (0 = window re-read from memory in pass 2).
+void pick_mh_geometry(d3d_ctx *c) {
+    const int npos = c->fh * c->fw;
+    int need = c->N > c->Dp ? c->N : c->Dp;
+    int nt_env = 0, mi_env = -1;
+    if (const char *e = getenv("D3D_MH_NT")) nt_env = atoi(e);
+    if (const char *e = getenv("D3D_MH_MAXIT")) mi_env = atoi(e);
+    const int cands[3] = {256, 512, 1024};
+    int nt = 1024;
+    for (int k = 0; k < 3; ++k) {
+        const int G = cands[k] / c->HL;
+        if (cands[k] < need || G < 1) continue;
+        const int iters = (npos + G - 1) / G;
+        if (iters <= 8) {
+            nt = cands[k];
+            break;
+        }
+    }
+    if ((nt_env == 256 || nt_env == 512 || nt_env == 1024) && nt_env >= need) nt = nt_env;
+    const int G = nt / c->HL;
+    const int iters = (npos + G - 1) / G;
+    int maxit = 0;
+    const int steps[4] = {4, 8, 16, 32};
+    for (int k = 0; k < 4; ++k)
+        if (iters <= steps[k]) {
+            maxit = steps[k];
+            break;
+        }
+    // override: 0 = re-read the window in pass 2; 4/8/16/32 accepted when they
+    // cover the window
+    if (mi_env == 0) maxit = 0;
+    if ((mi_env == 4 || mi_env == 8 || mi_env == 16 || mi_env == 32) && mi_env >= iters)
+        maxit = mi_env;
+    c->mh_nt = nt;
+    c->mh_maxit = maxit;
+}
+
+int build_colour_lists(d3d_ctx *c) {
+    const int ncol = c->fh * c->fw;
+    std::vector<int> list;
+    list.reserve((size_t)c->HW);
+    c->colour_off.assign(ncol + 1, 0);
+    for (int cy = 0; cy < c->fh; ++cy)
+        for (int cx = 0; cx < c->fw; ++cx) {
+            c->colour_off[cy * c->fw + cx] = (int)list.size();
+            for (int y = cy; y < c->H; y += c->fh)
+                for (int x = cx; x < c->W; x += c->fw)
+                    if (c->h_mask[(size_t)y * c->W + x]) list.push_back(y * c->W + x);
+        }
+    c->colour_off[ncol] = (int)list.size();
+    if (!list.empty())
+        HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice,
+                               c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+int d3d_version(void) { return D3D_VERSION; }
+
+const char *d3d_last_error(void) { return g_err.c_str(); }
+
+int d3d_device_count(int *count) {
+    NEED(count, D3D_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return D3D_OK;
+}
+
+int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int fw) {
+    NEED(out, D3D_ERR_INVALID, "ctx is NULL");
+    *out = nullptr;
+    NEED(D >= 1 && H >= 1 && W >= 1, D3D_ERR_INVALID, "cube shape (%d,%d,%d) must be positive", D,
+         H, W);
+    // lib/run.py:210-211
+    NEED(fh >= 1 && fw >= 1 && (fh & 1) && (fw & 1), D3D_ERR_INVALID,
+         "FSF *must* be of odd dimensions, got (%d,%d)", fh, fw);
+    NEED((long)H * W < (1L << 31) - 1, D3D_ERR_UNSUPPORTED, "too many spaxels");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(D3D_ERR_NO_DEVICE,
+                    "no HIP device available: libdeconv3d_hip has no CPU fallback");
+    }
+    NEED(device >= 0 && device < n, D3D_ERR_INVALID, "device %d out of range (%d visible)", device,
+         n);
+    HIP_TRY(hipSetDevice(device));
+
+    d3d_ctx *c = new (std::nothrow) d3d_ctx();
+    NEED(c, D3D_ERR_HIP, "out of host memory");
+    c->device = device;
+    c->D = D;
+    c->H = H;
+    c->W = W;
+    c->fh = fh;
+    c->fw = fw;
+    c->Dp = (D + 1) & ~1;
+    c->HL = c->Dp / 2;
+    c->N = next_pow2_ref(D);
+    c->HW = (long)H * W;
+    c->cube_elems = (size_t)c->HW * c->Dp;
+    if (c->N > 1024 || c->Dp > 1024) {
+        delete c;
+        return fail(D3D_ERR_UNSUPPORTED, "spectral depth %d exceeds the kernels' limit of 1024", D);
+    }
+    c->sp_nt = pick_nt(c->HL);
+    pick_mh_geometry(c);
+
+#define CTX_TRY(expr)                                                                 \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            d3d_ctx_destroy(c);                                                       \
+            return fail(D3D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+        }                                                                             \
+    } while (0)
+    CTX_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    CTX_TRY(hipEventCreate(&c->ev0));
+    CTX_TRY(hipEventCreate(&c->ev1));
+    for (int s = 0; s < D3D_SLOT_COUNT; ++s) {
+        CTX_TRY(hipMalloc(&c->slot[s], c->cube_elems * sizeof(double)));
+        CTX_TRY(hipMemsetAsync(c->slot[s], 0, c->cube_elems * sizeof(double), c->stream));
+    }
+    CTX_TRY(hipMalloc(&c->stage, (size_t)D * c->HW * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->stage2, (size_t)D * c->HW * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->params, (size_t)c->HW * 3 * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->mask, (size_t)c->HW));
+    CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->lsf_shift, (size_t)c->N * sizeof(int)));
+    CTX_TRY(hipMalloc(&c->lsf_weight, (size_t)c->N * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->dlog, (size_t)c->HW * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->hwbuf, (size_t)c->HW * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->scal, 16 * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->accepted, sizeof(unsigned long long)));
+    CTX_TRY(hipMalloc(&c->spx, (size_t)c->HW * sizeof(int)));
+    CTX_TRY(hipMemsetAsync(c->dlog, 0, (size_t)c->HW * sizeof(double), c->stream));
+    CTX_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
+    CTX_TRY(hipMemsetAsync(c->mask, 1, (size_t)c->HW, c->stream));
+    CTX_TRY(hipStreamSynchronize(c->stream));
+#undef CTX_TRY
+    c->h_mask.assign((size_t)c->HW, 1);
+    *out = c;
+    return D3D_OK;
+}
+
+int d3d_ctx_destroy(d3d_ctx *c) {
+    if (!c) return D3D_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < D3D_SLOT_COUNT; ++s)
+        if (c->slot[s]) (void)hipFree(c->slot[s]);
+    void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
+                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return D3D_OK;
+}
+
+int d3d_ctx_set_stream(d3d_ctx *c, void *hip_stream) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return D3D_OK;
+}
+
+int d3d_sync(d3d_ctx *c) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_timer_start(d3d_ctx *c) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return D3D_OK;
+}
+
+int d3d_timer_stop(d3d_ctx *c, double *ms) {
+    NEED(c && ms, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, c->ev0, c->ev1));
+    *ms = (double)f;
+    return D3D_OK;
+}
+
+int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
+    NEED(c && fsf, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->fsf, fsf, (size_t)c->fh * c->fw * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    std::vector<int> shift;
+    std::vector<double> weight;
+    if (lsf) {
+        // closed form of convolve_1d: lib/convolution.py:89-160, SURVEY 8(a) a3
+        const int N = c->N, D = c->D;
+        const int diff = N - D;
+        const int h = (diff & 1) ? diff / 2 + 1 : diff / 2;  // lib/convolution.py:149-153
+        double mx = 0.0;
+        for (int t = 0; t < D; ++t) mx = std::fmax(mx, std::fabs(lsf[t]));
+        const double cut = thr * mx;
+        for (int t = 0; t < D; ++t) {
+            if (!(std::fabs(lsf[t]) > cut)) continue;
+            int s = (N / 2 - h - t) % N;
+            if (s < 0) s += N;
+            shift.push_back(s);
+            weight.push_back(lsf[t]);
+        }
+        NEED(!shift.empty(), D3D_ERR_INVALID, "LSF has no non-zero tap");
+    }
+    c->ntaps = (int)shift.size();
+    if (c->ntaps) {
+        HIP_TRY(hipMemcpyAsync(c->lsf_shift, shift.data(), shift.size() * sizeof(int),
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->lsf_weight, weight.data(), weight.size() * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_taps = true;
+    c->err_valid = false;
+    return D3D_OK;
+}
+
+int d3d_set_data(d3d_ctx *c, const double *data, const double *var, double var_scalar,
+                 const uint8_t *mask) {
+    NEED(c && data, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->D * c->HW;
+    // mask: user mask AND no NaN anywhere in the spectrum (lib/run.py:153-162)
+    for (long s = 0; s < c->HW; ++s) c->h_mask[s] = mask ? (mask[s] == 1) : 1;
+    for (int z = 0; z < c->D; ++z) {
+        const double *pl = data + (size_t)z * c->HW;
+        for (long s = 0; s < c->HW; ++s)
+            if (pl[s] != pl[s]) c->h_mask[s] = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(c->mask, c->h_mask.data(), (size_t)c->HW, hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipMemcpyAsync(c->stage, data, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    double *dvar = nullptr;
+    if (var) {
+        // the 1/var staging reuses TMP1's storage when it is large enough; use
+        // a dedicated upload through stage2 to keep things simple.
+        HIP_TRY(hipMemcpyAsync(c->stage2, var, n * sizeof(double), hipMemcpyHostToDevice,
+                               c->stream));
+        dvar = c->stage2;
+    }
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    // in place: stage <- cleaned data, stage2 <- 1/var
+    hipLaunchKernelGGL(d3d::k_prepare_data, dim3(grid), dim3(256), 0, c->stream, c->stage,
+                       c->stage2, (const double *)dvar, var_scalar, (long)n);
+    HIP_TRY(hipGetLastError());
+    int rc = to_device_layout(c, c->stage, c->slot[D3D_SLOT_DATA]);
+    if (rc) return rc;
+    rc = to_device_layout(c, c->stage2, c->slot[D3D_SLOT_IVAR]);
+    if (rc) return rc;
+    rc = build_colour_lists(c);
+    if (rc) return rc;
+    c->have_data = true;
+    c->err_valid = false;
+    return D3D_OK;
+}
+
+int d3d_set_params(d3d_ctx *c, const double *params) {
+    NEED(c && params, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->params, params, (size_t)c->HW * 3 * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_params = true;
+    c->err_valid = false;
+    return D3D_OK;
+}
+
+int d3d_get_params(d3d_ctx *c, double *params) {
+    NEED(c && params, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_params, D3D_ERR_STATE, "parameters not set");
+    HIP_TRY(hipMemcpyAsync(params, c->params, (size_t)c->HW * 3 * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_build_clean(d3d_ctx *c, double *out) {
+    NEED(c && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_params, D3D_ERR_STATE, "parameters not set");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 0);
+    if (rc) return rc;
+    return download_cube(c, c->slot[D3D_SLOT_TMP0], out);
+}
+
+int d3d_convolve_slots(d3d_ctx *c, int src, int dst) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(src >= 0 && src < D3D_SLOT_COUNT && dst >= 0 && dst < D3D_SLOT_COUNT && src != dst,
+         D3D_ERR_INVALID, "bad slots %d -> %d", src, dst);
+    NEED(c->have_taps, D3D_ERR_STATE, "taps not set");
+    NEED(dst != D3D_SLOT_TMP1 && src != D3D_SLOT_TMP1, D3D_ERR_INVALID,
+         "SLOT_TMP1 is the convolution's intermediate");
+    HIP_TRY(hipSetDevice(c->device));
+    const double *in = c->slot[src];
+    if (c->ntaps > 0) {
+        int rc = launch_spectral(c, in, c->slot[D3D_SLOT_TMP1]);
+        if (rc) return rc;
+        in = c->slot[D3D_SLOT_TMP1];
+    }
+    return launch_spatial(c, in, c->slot[dst], nullptr);
+}
+
+int d3d_upload_slot(d3d_ctx *c, int slot, const double *cube) {
+    NEED(c && cube, D3D_ERR_INVALID, "NULL argument");
+    NEED(slot >= 0 && slot < D3D_SLOT_COUNT, D3D_ERR_INVALID, "bad slot %d", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = upload_cube(c, cube, c->slot[slot]);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (slot == D3D_SLOT_ERR) c->err_valid = true;
+    return D3D_OK;
+}
+
+int d3d_download_slot(d3d_ctx *c, int slot, double *cube) {
+    NEED(c && cube, D3D_ERR_INVALID, "NULL argument");
+    NEED(slot >= 0 && slot < D3D_SLOT_COUNT, D3D_ERR_INVALID, "bad slot %d", slot);
+    HIP_TRY(hipSetDevice(c->device));
+    return download_cube(c, c->slot[slot], cube);
+}
+
+int d3d_convolve(d3d_ctx *c, const double *in, double *out) {
+    NEED(c && in && out, D3D_ERR_INVALID, "NULL argument");
+    int rc = d3d_upload_slot(c, D3D_SLOT_TMP0, in);
+    if (rc) return rc;
+    rc = d3d_convolve_slots(c, D3D_SLOT_TMP0, D3D_SLOT_SIM);
+    if (rc) return rc;
+    return d3d_download_slot(c, D3D_SLOT_SIM, out);
+}
+
+int d3d_forward(d3d_ctx *c, double *out_sim) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps && c->have_params, D3D_ERR_STATE, "taps/parameters not set");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = forward_into(c, c->slot[D3D_SLOT_SIM], false);
+    if (rc) return rc;
+    if (out_sim) return download_cube(c, c->slot[D3D_SLOT_SIM], out_sim);
+    return D3D_OK;
+}
+
+int d3d_residual(d3d_ctx *c, double *out_err) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps && c->have_params && c->have_data, D3D_ERR_STATE,
+         "taps/data/parameters not set");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = forward_into(c, c->slot[D3D_SLOT_ERR], true);
+    if (rc) return rc;
+    c->err_valid = true;
+    if (out_err) return download_cube(c, c->slot[D3D_SLOT_ERR], out_err);
+    return D3D_OK;
+}
+
+int d3d_chi2_map(d3d_ctx *c, double *out_hw, double *total) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_data && c->err_valid, D3D_ERR_STATE, "residual not available");
+    HIP_TRY(hipSetDevice(c->device));
+    const unsigned grid = (unsigned)((c->HW + 3) / 4);
+    hipLaunchKernelGGL(d3d::k_chi2_map, dim3(grid), dim3(256), 0, c->stream,
+                       (const double *)c->slot[D3D_SLOT_ERR], (const double *)c->slot[D3D_SLOT_IVAR],
+                       c->hwbuf, c->HL, c->Dp, c->HW);
+    HIP_TRY(hipGetLastError());
+    if (total) {
+        hipLaunchKernelGGL(d3d::k_sum, dim3(1), dim3(1024), 0, c->stream, (const double *)c->hwbuf,
+                           c->HW, c->scal + 8);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(total, c->scal + 8, sizeof(double), hipMemcpyDeviceToHost,
+                               c->stream));
+    }
+    if (out_hw)
+        HIP_TRY(hipMemcpyAsync(out_hw, c->hwbuf, (size_t)c->HW * sizeof(double),
+                               hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_mh_config(d3d_ctx *c, const double min_b[3], const double max_b[3],
+                  const double jump_amp[3], double ra, uint64_t seed, int refresh_every) {
+    NEED(c && min_b && max_b && jump_amp, D3D_ERR_INVALID, "NULL argument");
+    for (int k = 0; k < 3; ++k)  // lib/run.py:244-245
+        NEED(!(min_b[k] > max_b[k]), D3D_ERR_INVALID, "Boundaries are inconsistent: min > max.");
+    NEED(ra > 0.0, D3D_ERR_INVALID, "gibbs_apriori_variance must be positive");
+    NEED(refresh_every >= 0, D3D_ERR_INVALID, "refresh_every must be >= 0");
+    for (int k = 0; k < 3; ++k) {
+        c->min_b[k] = min_b[k];
+        c->max_b[k] = max_b[k];
+        c->amp[k] = jump_amp[k];
+    }
+    c->amp[0] = 0.0;  // lib/run.py:261-262
+    c->ra = ra;
+    c->seed = seed;
+    c->refresh_every = refresh_every;
+    c->have_cfg = true;
+    return D3D_OK;
+}
+
+int d3d_window_stats(d3d_ctx *c, int y, int x, const double p_new[3], double out[5]) {
+    NEED(c && p_new && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_taps && c->have_data && c->have_params, D3D_ERR_STATE,
+         "taps/data/parameters not set");
+    NEED(y >= 0 && y < c->H && x >= 0 && x < c->W, D3D_ERR_INVALID, "spaxel (%d,%d) out of range",
+         y, x);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->err_valid) {
+        int rc = d3d_residual(c, nullptr);
+        if (rc) return rc;
+    }
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    P.probe = 1;
+    P.probe_sp = y * c->W + x;
+    P.probe_p[0] = p_new[0];
+    P.probe_p[1] = p_new[1];
+    P.probe_p[2] = p_new[2];
+    int rc = launch_mh(c, P, 1, 0);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->scal, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, double *chain_out,
+                  double *dlog_out, int64_t *accepted) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,
+         "taps/data/parameters/mh_config not set");
+    NEED(n_sweeps >= 0 && first_sweep >= 0, D3D_ERR_INVALID, "negative sweep count/index");
+    NEED(keep_one_in > 0, D3D_ERR_INVALID, "keep_one_in= MUST be a positive integer");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->err_valid) {
+        int rc = d3d_residual(c, nullptr);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const int ncol = c->fh * c->fw;
+    for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
+        for (int col = 0; col < ncol; ++col) {
+            const int cnt = c->colour_off[col + 1] - c->colour_off[col];
+            if (cnt <= 0) continue;
+            P.spx = c->spx + c->colour_off[col];
+            int rc = launch_mh(c, P, (unsigned)cnt, (uint32_t)s);
+            if (rc) return rc;
+        }
+        if (s % keep_one_in == 0) {  // lib/run.py:353, 430-432, 449-451
+            const size_t slot = (size_t)(s / keep_one_in);
+            if (chain_out)
+                HIP_TRY(hipMemcpyAsync(chain_out + slot * c->HW * 3, c->params,
+                                       (size_t)c->HW * 3 * sizeof(double), hipMemcpyDeviceToHost,
+                                       c->stream));
+            if (dlog_out)
+                HIP_TRY(hipMemcpyAsync(dlog_out + slot * c->HW, c->dlog,
+                                       (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
+                                       c->stream));
+        }
+        // lib/run.py:521-534: squash the error creep with a fresh residual
+        if (c->refresh_every > 0 && s % c->refresh_every == 0) {
+            int rc = forward_into(c, c->slot[D3D_SLOT_ERR], true);
+            if (rc) return rc;
+        }
+    }
+    unsigned long long acc = 0;
+    HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (accepted) *accepted = (int64_t)acc;
+    return D3D_OK;
+}
+
+int d3d_get_dlog(d3d_ctx *c, double *out_hw) {
+    NEED(c && out_hw, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipMemcpyAsync(out_hw, c->dlog, (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_colour_count(d3d_ctx *c, int colour, int *count) {
+    NEED(c && count, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_data, D3D_ERR_STATE, "data not set");
+    NEED(colour >= 0 && colour < c->fh * c->fw, D3D_ERR_INVALID, "colour %d out of range", colour);
+    *count = c->colour_off[colour + 1] - c->colour_off[colour];
+    return D3D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,631 @@
+// HIP kernels of the deconv3d likelihood path for gfx950 (MI355X, wave64).
+//
+// Device layout.  The reference stores cubes (D,H,W) with x fastest
+// (lib/run.py:146-149).  On the device every cube is stored SPECTRUM-CONTIGUOUS,
+// (H, W, Dp) with Dp = D rounded up to even and zero padding: one spaxel's
+// spectrum is one contiguous run (1 KiB at D=128), so
+//   * the MH update's FSF window is fh runs of fw*Dp contiguous doubles,
+//   * the spectral (LSF) pass has z along the lanes of a wavefront,
+//   * the spatial (FSF) pass reads whole spectra, 16 B per lane, coalesced.
+// A thread always owns a z-PAIR (one double2 = one 16-byte access).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "d3d_rng.h"
+
+namespace d3d {
+
+// ------------------------------------------------------------------------- //
+// layout conversion                                                          //
+// ------------------------------------------------------------------------- //
+
+// (D, HW) host layout -> (HW, Dp) device layout, zero padded.  32x32 LDS tile.
+__global__ __launch_bounds__(256) void k_to_device_layout(const double *__restrict__ src,
+                                                           double *__restrict__ dst, int D,
+                                                           int Dp, long HW) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const long s0 = (long)blockIdx.x * 32;
+    const int z0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int z = z0 + ty + k;
+        const long s = s0 + tx;
+        tile[ty + k][tx] = (z < D && s < HW) ? src[(long)z * HW + s] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const long s = s0 + ty + k;
+        const int z = z0 + tx;
+        if (s < HW && z < Dp) dst[s * Dp + z] = tile[tx][ty + k];
+    }
+}
+
+// (HW, Dp) device layout -> (D, HW) host layout.
+__global__ __launch_bounds__(256) void k_to_host_layout(const double *__restrict__ src,
+                                                         double *__restrict__ dst, int D, int Dp,
+                                                         long HW) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long s0 = (long)blockIdx.x * 32;
+    const int z0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const long s = s0 + ty + k;
+        const int z = z0 + tx;
+        tile[ty + k][tx] = (s < HW && z < Dp) ? src[s * Dp + z] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int z = z0 + ty + k;
+        const long s = s0 + tx;
+        if (z < D && s < HW) dst[(long)z * HW + s] = tile[tx][ty + k];
+    }
+}
+
+// data/variance fix-ups of lib/run.py:171-200 + SURVEY appendix A, elementwise
+// in host layout: var==0 -> 1e12; NaN voxel -> data 0, 1/var 0.
+__global__ void k_prepare_data(double *__restrict__ data, double *__restrict__ ivar,
+                               const double *__restrict__ var, double var_scalar, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = var ? var[i] : var_scalar;
+    double d = data[i];
+    if (v == 0.0) v = 1e12;
+    double iv = 1.0 / v;
+    if (d != d || v != v) {
+        d = 0.0;
+        iv = 0.0;
+    }
+    data[i] = d;
+    ivar[i] = iv;
+}
+
+// ------------------------------------------------------------------------- //
+// line model + spectral (LSF) pass                                           //
+// ------------------------------------------------------------------------- //
+
+// lib/line_models.py:109 with unit amplitude; w == 0 would be 0/0 in the
+// reference -- here it degenerates to a delta at z == c.
+__device__ __forceinline__ double unit_gaussian(double z, double c, double w) {
+    const double w2 = 2.0 * w * w;
+    const double d = z - c;
+    return (w2 > 0.0) ? exp(-(d * d) / w2) : ((d == 0.0) ? 1.0 : 0.0);
+}
+
+struct SpectralArgs {
+    int D, Dp, HL, N, ntaps;
+    long nspax;
+    const int *shift;      // [ntaps]  (N/2 - h - t) mod N
+    const double *weight;  // [ntaps]
+};
+
+// Closed form of convolve_1d (lib/convolution.py:89-120):
+// out[k] = sum_t w_t * ext[(k + s_t) mod N], ext zero beyond D, N power of 2.
+__device__ __forceinline__ double lsf_apply(const double *ext, int k, const SpectralArgs &A) {
+    double acc = 0.0;
+    for (int t = 0; t < A.ntaps; ++t) acc += A.weight[t] * ext[(k + A.shift[t]) & (A.N - 1)];
+    return acc;
+}
+
+// params (H,W,3) -> cube of LSF-convolved lines (mode 1) or clean lines
+// (mode 0), zero where mask == 0.  lib/run.py:597-621 and :1011-1024.
+// One group of HL threads per spaxel, G groups per block, ext[] in LDS.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lines(SpectralArgs A, const double *__restrict__ params,
+                                              const uint8_t *__restrict__ mask,
+                                              double *__restrict__ out, int convolved) {
+    extern __shared__ double smem[];
+    const int G = NT / A.HL;
+    const int g = threadIdx.x / A.HL, zl = threadIdx.x - g * A.HL;
+    const long sp = (long)blockIdx.x * G + g;
+    const bool active = (g < G) && (sp < A.nspax);
+    double *ext = smem + (size_t)g * A.N;
+    double a = 0, c = 0, w = 1;
+    bool live = false;
+    if (active) {
+        live = mask[sp] != 0;
+        a = params[sp * 3 + 0];
+        c = params[sp * 3 + 1];
+        w = params[sp * 3 + 2];
+    }
+    const bool use_lsf = convolved && A.ntaps > 0;
+    double2 v = make_double2(0.0, 0.0);
+    if (active && live) {
+        const int z = 2 * zl;
+        v.x = (z < A.D) ? a * unit_gaussian((double)z, c, w) : 0.0;
+        v.y = (z + 1 < A.D) ? a * unit_gaussian((double)(z + 1), c, w) : 0.0;
+    }
+    if (use_lsf) {
+        if (active) {
+            for (int j = 2 * zl; j < A.N; j += 2 * A.HL) {
+                ext[j] = 0.0;
+                ext[j + 1] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            ext[2 * zl] = v.x;
+            ext[2 * zl + 1] = v.y;
+        }
+        __syncthreads();
+        if (active && live) {
+            const int z = 2 * zl;
+            v.x = (z < A.D) ? lsf_apply(ext, z, A) : 0.0;
+            v.y = (z + 1 < A.D) ? lsf_apply(ext, z + 1, A) : 0.0;
+        }
+    }
+    if (active) *reinterpret_cast<double2 *>(out + sp * A.Dp + 2 * zl) = v;
+}
+
+// Spectral pass of an arbitrary cube: out[sp,:] = LSF (*) in[sp,:].
+template <int NT>
+__global__ __launch_bounds__(NT) void k_spectral(SpectralArgs A, const double *__restrict__ in,
+                                                 double *__restrict__ out) {
+    extern __shared__ double smem[];
+    const int G = NT / A.HL;
+    const int g = threadIdx.x / A.HL, zl = threadIdx.x - g * A.HL;
+    const long sp = (long)blockIdx.x * G + g;
+    const bool active = (g < G) && (sp < A.nspax);
+    double *ext = smem + (size_t)g * A.N;
+    double2 v = make_double2(0.0, 0.0);
+    if (active) {
+        v = *reinterpret_cast<const double2 *>(in + sp * A.Dp + 2 * zl);
+        for (int j = 2 * zl; j < A.N; j += 2 * A.HL) {
+            ext[j] = 0.0;
+            ext[j + 1] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (active) {
+        const int z = 2 * zl;
+        ext[z] = (z < A.D) ? v.x : 0.0;
+        ext[z + 1] = (z + 1 < A.D) ? v.y : 0.0;
+    }
+    __syncthreads();
+    if (active) {
+        const int z = 2 * zl;
+        v.x = (z < A.D) ? lsf_apply(ext, z, A) : 0.0;
+        v.y = (z + 1 < A.D) ? lsf_apply(ext, z + 1, A) : 0.0;
+        *reinterpret_cast<double2 *>(out + sp * A.Dp + 2 * zl) = v;
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// spatial (FSF) pass: true 2-D convolution, zero boundary, 'same' size        //
+// (scipy.signal.convolve2d(..., mode='same') of lib/run.py:1027-1029)         //
+//   out[Y,X] = sum_{j,i} fsf[j,i] * in[Y - j + fhh, X - i + fhw]              //
+// ------------------------------------------------------------------------- //
+
+struct SpatialArgs {
+    int Dp, HL, H, W, fh, fw;
+    const double *fsf;   // [fh*fw]
+    const double *data;  // residual epilogue: out = data - conv (or NULL)
+};
+
+// Register-tiled: a thread owns one z-pair and TX consecutive x outputs of one
+// row; per tap row it loads TX+FW-1 inputs and issues FW*TX double2 FMAs.
+// Taps are wave-uniform (scalar loads).  Lanes run along z: every global
+// access is a contiguous 16 B/lane run.
+template <int NT, int FW, int TX>
+__global__ __launch_bounds__(NT) void k_spatial(SpatialArgs A, const double *__restrict__ in,
+                                                double *__restrict__ out) {
+    const int S = NT / A.HL;  // strips per block
+    const int s = threadIdx.x / A.HL, zl = threadIdx.x - s * A.HL;
+    const int nxs = (A.W + TX - 1) / TX;
+    const long strip = (long)blockIdx.x * S + s;
+    if (s >= S || strip >= (long)A.H * nxs) return;
+    const int y = (int)(strip / nxs);
+    const int x0 = (int)(strip - (long)y * nxs) * TX;
+    constexpr int FHW = (FW - 1) / 2;
+    const int fhh = (A.fh - 1) / 2;
+
+    double2 acc[TX];
+#pragma unroll
+    for (int t = 0; t < TX; ++t) acc[t] = make_double2(0.0, 0.0);
+
+    for (int j = 0; j < A.fh; ++j) {
+        const int yy = y - j + fhh;
+        if (yy < 0 || yy >= A.H) continue;
+        double2 row[TX + FW - 1];
+        const double *base = in + ((long)yy * A.W) * A.Dp + 2 * zl;
+#pragma unroll
+        for (int i = 0; i < TX + FW - 1; ++i) {
+            const int xx = x0 - FHW + i;
+            row[i] = (xx >= 0 && xx < A.W) ? *reinterpret_cast<const double2 *>(base + (long)xx * A.Dp)
+                                           : make_double2(0.0, 0.0);
+        }
+        const double *taps = A.fsf + j * FW;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) {
+            const double tap = taps[i];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                acc[t].x = fma(tap, row[t + FW - 1 - i].x, acc[t].x);
+                acc[t].y = fma(tap, row[t + FW - 1 - i].y, acc[t].y);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TX; ++t) {
+        const int xo = x0 + t;
+        if (xo < A.W) {
+            const long o = ((long)y * A.W + xo) * A.Dp + 2 * zl;
+            double2 r = acc[t];
+            if (A.data) {
+                const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+                r.x = d.x - r.x;
+                r.y = d.y - r.y;
+            }
+            *reinterpret_cast<double2 *>(out + o) = r;
+        }
+    }
+}
+
+// Any-size fallback: one output z-pair per thread, loops over all taps.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_spatial_generic(SpatialArgs A,
+                                                        const double *__restrict__ in,
+                                                        double *__restrict__ out) {
+    const int S = NT / A.HL;
+    const int s = threadIdx.x / A.HL, zl = threadIdx.x - s * A.HL;
+    const long sp = (long)blockIdx.x * S + s;
+    if (s >= S || sp >= (long)A.H * A.W) return;
+    const int y = (int)(sp / A.W), x = (int)(sp - (long)y * A.W);
+    const int fhh = (A.fh - 1) / 2, fhw = (A.fw - 1) / 2;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int j = 0; j < A.fh; ++j) {
+        const int yy = y - j + fhh;
+        if (yy < 0 || yy >= A.H) continue;
+        for (int i = 0; i < A.fw; ++i) {
+            const int xx = x - i + fhw;
+            if (xx < 0 || xx >= A.W) continue;
+            const double tap = A.fsf[j * A.fw + i];
+            const double2 v =
+                *reinterpret_cast<const double2 *>(in + ((long)yy * A.W + xx) * A.Dp + 2 * zl);
+            acc.x = fma(tap, v.x, acc.x);
+            acc.y = fma(tap, v.y, acc.y);
+        }
+    }
+    const long o = sp * A.Dp + 2 * zl;
+    if (A.data) {
+        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+        acc.x = d.x - acc.x;
+        acc.y = d.y - acc.y;
+    }
+    *reinterpret_cast<double2 *>(out + o) = acc;
+}
+
+// ------------------------------------------------------------------------- //
+// chi2 map                                                                    //
+// ------------------------------------------------------------------------- //
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// out[sp] = 0.5 * sum_z err^2 * ivar (lib/run.py:423 per spectrum); one wave
+// per spaxel.
+__global__ __launch_bounds__(256) void k_chi2_map(const double *__restrict__ err,
+                                                   const double *__restrict__ ivar,
+                                                   double *__restrict__ out, int HL, int Dp,
+                                                   long nspax) {
+    const int lane = threadIdx.x & 63;
+    const long sp = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sp >= nspax) return;
+    double acc = 0.0;
+    for (int zl = lane; zl < HL; zl += 64) {
+        const double2 e = *reinterpret_cast<const double2 *>(err + sp * Dp + 2 * zl);
+        const double2 v = *reinterpret_cast<const double2 *>(ivar + sp * Dp + 2 * zl);
+        acc = fma(e.x * e.x, v.x, acc);
+        acc = fma(e.y * e.y, v.y, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[sp] = 0.5 * acc;
+}
+
+// Deterministic single-block sum of n doubles.
+__global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long n,
+                                               double *__restrict__ out) {
+    __shared__ double part[16];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += part[i];
+        *out = t;
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// MH-within-Gibbs update of one colour class (lib/run.py:367-519)            //
+// ------------------------------------------------------------------------- //
+//
+// One workgroup per spaxel.  With e = err, v = 1/var, f = fsf over the window
+// and E_old/E_new the unit-amplitude LSF-convolved lines of the current /
+// proposed (c,w), everything the reference computes from full-cube
+// temporaries follows from three per-channel window sums
+//     A[z] = sum_pos f v e,   B[z] = sum_pos f^2 v,   C[z] = sum_pos v e^2 :
+//   ar_old          = 1/2 sum_z C                                  (run.py:423)
+//   ar_old - ar_new = -sum_z d A - 1/2 sum_z d^2 B, d = a (E_old - E_new)  (:426)
+//   sum ek^2/var    = sum_z E^2 B,  sum ek ul/var = sum_z E (A + a E_old B) (:492-493)
+// so ONE pass over the err and 1/var windows suffices; the err window stays in
+// registers and is written back once as e + f (a E_old - r E_end)  (:508-515).
+// HBM traffic per update = read err + read ivar + write err = 3*D*fh*fw*8 B.
+
+struct MHArgs {
+    int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
+    double *err;
+    const double *ivar;
+    double *params;
+    const double *fsf;
+    const int *shift;
+    const double *weight;
+    double *dlog;
+    unsigned long long *accepted;
+    const int *spx;  // spaxel list of this colour (global linear indices y*W+x)
+    double min_b[3], max_b[3], amp[3];
+    double ra;
+    uint64_t seed;
+    // probe mode (d3d_window_stats): evaluate probe_p at spaxel probe_sp, write
+    // 5 doubles to probe_out, modify nothing.
+    int probe;
+    int probe_sp;
+    double probe_p[3];
+    double *probe_out;
+};
+
+__host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos) {
+    const int G = NT / HL;
+    return (size_t)npos + (size_t)G * 3 * Dp + 2 * (size_t)N + Dp + 8 * (NT / 64) + 8;
+}
+
+template <int NT, int MAXIT>
+__global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp, N = P.N, D = P.D;
+    const int G = NT / HL;
+    const int g = tid / HL, zl = tid - g * HL;
+    const bool active = g < G;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+
+    double *s_fsf = smem;
+    double *s_red = s_fsf + P.npos;
+    double *s_gO = s_red + (size_t)G * 3 * Dp;
+    double *s_gN = s_gO + N;
+    double *s_G = s_gN + N;
+    double *s_sum = s_G + Dp;
+
+    const int sp = P.probe ? P.probe_sp : P.spx[blockIdx.x];
+    const int y = sp / P.W, x = sp - y * P.W;
+
+    for (int p = tid; p < P.npos; p += NT) s_fsf[p] = P.fsf[p];
+    __syncthreads();
+
+    // ---- pass 1: window sums, err window kept in registers ----------------
+    constexpr int NREG = MAXIT > 0 ? MAXIT : 1;
+    double2 ereg[NREG];
+    double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+    if constexpr (MAXIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NREG; ++it) {
+            const int p = g + it * G;
+            const int dy = p / P.fw, dx = p - dy * P.fw;
+            const int yy = y + dy - fhh, xx = x + dx - fhw;
+            const bool ok = active && p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            double2 e = make_double2(0.0, 0.0), v = e;
+            double f = 0.0;
+            if (ok) {
+                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+                e = *reinterpret_cast<const double2 *>(P.err + idx);
+                v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                f = s_fsf[p];
+            }
+            ereg[it] = e;
+            const double fvx = f * v.x, fvy = f * v.y;
+            sA.x = fma(fvx, e.x, sA.x);
+            sA.y = fma(fvy, e.y, sA.y);
+            sB.x = fma(f, fvx, sB.x);
+            sB.y = fma(f, fvy, sB.y);
+            sC.x = fma(v.x * e.x, e.x, sC.x);
+            sC.y = fma(v.y * e.y, e.y, sC.y);
+        }
+    } else {
+        if (active) {
+            for (int p = g; p < P.npos; p += G) {
+                const int dy = p / P.fw, dx = p - dy * P.fw;
+                const int yy = y + dy - fhh, xx = x + dx - fhw;
+                if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+                const double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                const double f = s_fsf[p];
+                const double fvx = f * v.x, fvy = f * v.y;
+                sA.x = fma(fvx, e.x, sA.x);
+                sA.y = fma(fvy, e.y, sA.y);
+                sB.x = fma(f, fvx, sB.x);
+                sB.y = fma(f, fvy, sB.y);
+                sC.x = fma(v.x * e.x, e.x, sC.x);
+                sC.y = fma(v.y * e.y, e.y, sC.y);
+            }
+        }
+    }
+    if (active) {
+        double *r = s_red + (size_t)g * 3 * Dp + 2 * zl;
+        r[0] = sA.x;
+        r[1] = sA.y;
+        r[Dp] = sB.x;
+        r[Dp + 1] = sB.y;
+        r[2 * Dp] = sC.x;
+        r[2 * Dp + 1] = sC.y;
+    }
+
+    // ---- proposal (every thread computes the same numbers) ----------------
+    const double a_old = P.params[(long)sp * 3 + 0];
+    const double c_old = P.params[(long)sp * 3 + 1];
+    const double w_old = P.params[(long)sp * 3 + 2];
+    double pn[3];
+    double u_acc = 0.5;
+    if (P.probe) {
+        pn[0] = P.probe_p[0];
+        pn[1] = P.probe_p[1];
+        pn[2] = P.probe_p[2];
+    } else {
+        // lib/run.py:570-579: p + amp * tan(U(-pi/2, pi/2))
+        const U2 u0 = philox_pair(P.seed, (uint32_t)sp, sweep, BLK_JUMP_AC);
+        const U2 u1 = philox_pair(P.seed, (uint32_t)sp, sweep, BLK_JUMP_W);
+        const double PI = 3.141592653589793;
+        pn[0] = a_old + P.amp[0] * tan(PI * (u0.x - 0.5));
+        pn[1] = c_old + P.amp[1] * tan(PI * (u0.y - 0.5));
+        pn[2] = w_old + P.amp[2] * tan(PI * (u1.x - 0.5));
+        u_acc = u1.y;
+    }
+    // lib/run.py:379-384
+    bool oob = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) oob = oob || (pn[k] < P.min_b[k]) || (pn[k] > P.max_b[k]);
+
+    // ---- unit lines of old and new (c,w), zero-extended to N ---------------
+    if (tid < N) {
+        s_gO[tid] = (tid < D) ? unit_gaussian((double)tid, c_old, w_old) : 0.0;
+        s_gN[tid] = (tid < D) ? unit_gaussian((double)tid, pn[1], pn[2]) : 0.0;
+    }
+    __syncthreads();
+
+    // ---- per-channel totals and LSF pass (thread t <-> channel t) ----------
+    double EO = 0.0, EN = 0.0, Az = 0.0, Bz = 0.0, Cz = 0.0;
+    if (tid < D) {
+        for (int gg = 0; gg < G; ++gg) {
+            const double *r = s_red + (size_t)gg * 3 * Dp + tid;
+            Az += r[0];
+            Bz += r[Dp];
+            Cz += r[2 * Dp];
+        }
+        if (P.ntaps > 0) {
+            for (int t = 0; t < P.ntaps; ++t) {
+                const int j = (tid + P.shift[t]) & (N - 1);
+                const double wt = P.weight[t];
+                EO = fma(wt, s_gO[j], EO);
+                EN = fma(wt, s_gN[j], EN);
+            }
+        } else {
+            EO = s_gO[tid];
+            EN = s_gN[tid];
+        }
+    }
+    // the proposal keeps the amplitude unless amp[0] != 0 (never with Gibbs)
+    const double a_new = pn[0];
+    const double Lo = a_old * EO;
+    const double d = Lo - a_new * EN;  // old minus new contribution per unit f
+    const double ulB = Az + Lo * Bz;   // sum_pos f v ul
+    double sums[7];
+    sums[0] = d * Az;
+    sums[1] = d * d * Bz;
+    sums[2] = Cz;
+    sums[3] = EO * EO * Bz;
+    sums[4] = EO * ulB;
+    sums[5] = EN * EN * Bz;
+    sums[6] = EN * ulB;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sums[k] = wave_sum(sums[k]);
+    const int wave = tid >> 6, nwaves = NT / 64;
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) s_sum[wave * 8 + k] = sums[k];
+    }
+    __syncthreads();
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double t = 0.0;
+        for (int wv = 0; wv < nwaves; ++wv) t += s_sum[wv * 8 + k];
+        tot[k] = t;
+    }
+
+    const double ar_old = 0.5 * tot[2];
+    const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
+
+    if (P.probe) {
+        if (tid == 0) {
+            P.probe_out[0] = ar_old;
+            P.probe_out[1] = ar_old - delta;
+            P.probe_out[2] = delta;
+            P.probe_out[3] = tot[3];
+            P.probe_out[4] = tot[4];
+        }
+        return;
+    }
+
+    // ---- MH accept (lib/run.py:435-445) ------------------------------------
+    const bool accept = (log(u_acc) < delta) && !oob;
+    const double a_cur = accept ? a_new : a_old;
+    const double c_end = accept ? pn[1] : c_old;
+    const double w_end = accept ? pn[2] : w_old;
+    const double Eend = accept ? EN : EO;
+    // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
+    const double s_ee = accept ? tot[5] : tot[3];
+    const double s_eu = accept ? tot[6] : tot[4];
+
+    // ---- Gibbs draw of the amplitude (lib/run.py:456-499) ------------------
+    const double ro = P.ra / (1.0 + P.ra * s_ee);
+    const double mu = ro * s_eu;
+    uint32_t blk = BLK_GIBBS;
+    const double r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, (uint32_t)sp,
+                                      sweep, &blk);
+    (void)a_cur;
+
+    // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
+    if (tid < Dp) s_G[tid] = (tid < D) ? (Lo - r * Eend) : 0.0;
+    if (tid == 0) {
+        P.params[(long)sp * 3 + 0] = r;
+        P.params[(long)sp * 3 + 1] = c_end;
+        P.params[(long)sp * 3 + 2] = w_end;
+        P.dlog[sp] = delta;
+        if (accept) atomicAdd(P.accepted, 1ULL);
+    }
+    __syncthreads();
+
+    // ---- pass 2: write the window back ------------------------------------
+    if (!active) return;
+    const double2 Gz = *reinterpret_cast<const double2 *>(s_G + 2 * zl);
+    if constexpr (MAXIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NREG; ++it) {
+            const int p = g + it * G;
+            const int dy = p / P.fw, dx = p - dy * P.fw;
+            const int yy = y + dy - fhh, xx = x + dx - fhw;
+            const bool ok = p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            if (ok) {
+                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+                const double f = s_fsf[p];
+                double2 e = ereg[it];
+                e.x = fma(f, Gz.x, e.x);
+                e.y = fma(f, Gz.y, e.y);
+                *reinterpret_cast<double2 *>(P.err + idx) = e;
+            }
+        }
+    } else {
+        for (int p = g; p < P.npos; p += G) {
+            const int dy = p / P.fw, dx = p - dy * P.fw;
+            const int yy = y + dy - fhh, xx = x + dx - fhw;
+            if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+            const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+            const double f = s_fsf[p];
+            double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+            e.x = fma(f, Gz.x, e.x);
+            e.y = fma(f, Gz.y, e.y);
+            *reinterpret_cast<double2 *>(P.err + idx) = e;
+        }
+    }
+}
+
+}  // namespace d3d

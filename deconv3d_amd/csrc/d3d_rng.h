@@ -1,0 +1,117 @@
+// Counter-based RNG and truncated-normal sampler of the MH-within-Gibbs kernel.
+//
+// The reference draws from the unseeded global numpy RNG (lib/run.py:313,435,
+// 578) and from Chopin's table sampler (lib/rtnorm.py:95-224, GPL tables).
+// Neither is reproduced: the device uses Philox4x32-10 keyed by
+// (seed, global spaxel index, sweep, block) so that an update's random numbers
+// do not depend on launch geometry, tiling or scan order, and an own
+// truncated-normal sampler with the same distribution as rtnorm.  The oracle
+// (oracle/deconv3d_oracle.py: philox_pair, truncated_normal) restates both bit
+// for bit / formula for formula.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace d3d {
+
+struct U2 {
+    double x, y;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += W0;
+        k1 += W1;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+// (0,1) double from 64 random bits: ((u >> 11) + 0.5) * 2^-53
+__device__ __forceinline__ double u64_to_unit(uint64_t u) {
+    return ((double)(u >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+
+// Two uniforms of block `block` of the update (spaxel, sweep).
+__device__ __forceinline__ U2 philox_pair(uint64_t seed, uint32_t spaxel, uint32_t sweep,
+                                          uint32_t block) {
+    uint32_t r[4];
+    philox4x32_10(spaxel, sweep, block, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    U2 u;
+    u.x = u64_to_unit(((uint64_t)r[1] << 32) | r[0]);
+    u.y = u64_to_unit(((uint64_t)r[3] << 32) | r[2]);
+    return u;
+}
+
+// Philox block layout of one spaxel update (oracle: BLK_*).
+constexpr uint32_t BLK_JUMP_AC = 0;  // (u_a, u_c)
+constexpr uint32_t BLK_JUMP_W = 1;   // (u_w, u_accept)
+constexpr uint32_t BLK_GIBBS = 2;    // truncated normal: 2, 3, ...
+
+constexpr double TN_TAIL = 6.0;
+constexpr double SQRT2 = 1.4142135623730951;
+
+// N(0,1) truncated to [alpha, beta]; consumes blocks from *blk upwards.
+__device__ inline double truncated_standard_normal(double alpha, double beta, uint64_t seed,
+                                                   uint32_t spaxel, uint32_t sweep,
+                                                   uint32_t *blk) {
+    double sign = 1.0;
+    if (beta <= 0.0) {  // mirror so that the interval reaches into x > 0
+        const double t = -alpha;
+        alpha = -beta;
+        beta = t;
+        sign = -1.0;
+    }
+    double z;
+    if (alpha >= TN_TAIL) {
+        // Robert (1995): translated exponential proposal, rate lam
+        const double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
+        z = alpha;
+        for (int it = 0; it < 1000; ++it) {
+            const U2 u = philox_pair(seed, spaxel, sweep, (*blk)++);
+            const double zz = alpha - log(u.x) / lam;
+            if (zz <= beta && log(u.y) <= -0.5 * (zz - lam) * (zz - lam)) {
+                z = zz;
+                break;
+            }
+        }
+        return sign * z;
+    }
+    const U2 u = philox_pair(seed, spaxel, sweep, (*blk)++);
+    if (alpha > 0.0) {
+        const double qa = 0.5 * erfc(alpha / SQRT2);
+        const double qb = 0.5 * erfc(beta / SQRT2);
+        const double q = qa - u.x * (qa - qb);
+        z = SQRT2 * erfcinv(2.0 * q);
+    } else {
+        const double pa = normcdf(alpha);
+        const double pb = normcdf(beta);
+        z = normcdfinv(pa + u.x * (pb - pa));
+    }
+    z = fmin(fmax(z, alpha), beta);
+    return sign * z;
+}
+
+// TN(lo, hi; mu, sigma): distribution of rtnorm(lo, hi, mu, sigma), lib/rtnorm.py:21-92.
+__device__ inline double truncated_normal(double lo, double hi, double mu, double sigma,
+                                          uint64_t seed, uint32_t spaxel, uint32_t sweep,
+                                          uint32_t *blk) {
+    const double alpha = (lo - mu) / sigma;
+    const double beta = (hi - mu) / sigma;
+    const double z = truncated_standard_normal(alpha, beta, seed, spaxel, sweep, blk);
+    return fmin(fmax(mu + sigma * z, lo), hi);
+}
+
+}  // namespace d3d

@@ -1,0 +1,158 @@
+/*
+ * deconv3d_hip.h -- C ABI of libdeconv3d_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-iteration likelihood path of irap-omp/deconv3d.
+ * The reference has NO FFI of its own (it is pure python/numpy),
+ * so every entry point below cites the reference python code it replaces
+ * (paths relative to the reference root).  The reference-side binding a
+ * maintainer would add (a ctypes stub inside lib/run.py) is shown in
+ * INTEGRATION.md; the build's own host side is deconv3d_amd/_lib.py.
+ *
+ * Conventions
+ *   - all floating point is IEEE fp64; host arrays are C-contiguous and
+ *     caller-owned, in the reference's layouts:
+ *         cube   (D, H, W)   x fastest            lib/run.py:146-149
+ *         params (H, W, 3)   (a, c, w)            lib/line_models.py:70-71
+ *         fsf    (fh, fw)    odd sizes            lib/run.py:209-211
+ *         lsf    [D]         centred as lib/spread_functions.py:251
+ *         mask   (H, W)      uint8, 1 = iterate   lib/run.py:151-165
+ *   - the library copies host data to HBM and never retains a host pointer
+ *     after the call returns;
+ *   - every function returns 0 on success and a negative d3d_status on error;
+ *     d3d_last_error() returns a thread-local human readable message;
+ *   - a d3d_ctx is bound to one device and one HIP stream; it is not
+ *     thread-safe; use one ctx per device (one process per GPU in multi-GPU
+ *     runs).  There is NO CPU fallback: without a HIP device d3d_ctx_create
+ *     fails with D3D_ERR_NO_DEVICE.
+ */
+#ifndef DECONV3D_HIP_H
+#define DECONV3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct d3d_ctx d3d_ctx;
+
+typedef enum d3d_status {
+    D3D_OK = 0,
+    D3D_ERR_INVALID = -1,    /* bad argument / shape (python: ValueError)   */
+    D3D_ERR_NO_DEVICE = -2,  /* no usable HIP device                        */
+    D3D_ERR_HIP = -3,        /* a HIP runtime call failed                   */
+    D3D_ERR_STATE = -4,      /* call sequence error (taps/data/params unset)*/
+    D3D_ERR_UNSUPPORTED = -5 /* shape outside the kernels' limits           */
+} d3d_status;
+
+/* Device cubes owned by a ctx, addressable through the *_slot functions.   */
+typedef enum d3d_slot {
+    D3D_SLOT_DATA = 0,   /* observed cube (NaN -> 0 with ivar 0)             */
+    D3D_SLOT_IVAR = 1,   /* 1/variance                                       */
+    D3D_SLOT_ERR = 2,    /* residual data - sim carried by the MH loop       */
+    D3D_SLOT_SIM = 3,    /* last forward model                               */
+    D3D_SLOT_TMP0 = 4,   /* scratch (LSF-convolved lines / user cube)        */
+    D3D_SLOT_TMP1 = 5,   /* scratch                                          */
+    D3D_SLOT_COUNT = 6
+} d3d_slot;
+
+/* library version: major*10000 + minor*100 + patch */
+int d3d_version(void);
+/* thread-local message of the last failing call ("" if none) */
+const char *d3d_last_error(void);
+/* number of visible HIP devices (0 and D3D_OK when there is none) */
+int d3d_device_count(int *count);
+
+/* ---- context ----------------------------------------------------------- */
+
+/* Replaces the shape bookkeeping of Run.__init__, lib/run.py:145-149,219-224.
+ * D,H,W: cube shape; fh,fw: FSF shape (odd).  Allocates all device cubes. */
+int d3d_ctx_create(d3d_ctx **ctx, int device, int D, int H, int W, int fh, int fw);
+int d3d_ctx_destroy(d3d_ctx *ctx);
+/* Run on a caller-owned HIP stream (e.g. torch's current stream) instead of
+ * the ctx's own; NULL restores the own stream. */
+int d3d_ctx_set_stream(d3d_ctx *ctx, void *hip_stream);
+/* Block until everything queued on the ctx stream has finished. */
+int d3d_sync(d3d_ctx *ctx);
+/* HIP-event stopwatch on the ctx stream (for bench.py's roofline leg). */
+int d3d_timer_start(d3d_ctx *ctx);
+int d3d_timer_stop(d3d_ctx *ctx, double *elapsed_ms);
+
+/* ---- inputs ------------------------------------------------------------ */
+
+/* Taps produced once per run by instrument.fsf.as_image / lsf.as_vector,
+ * lib/run.py:207-211.  lsf may be NULL (no spectral pass: lib/run.py:675-676,
+ * 1015-1016).  LSF taps with |lsf[t]| <= lsf_rel_threshold*max|lsf| are
+ * dropped (0 keeps every non-zero tap; the python host uses 1e-20). */
+int d3d_set_taps(d3d_ctx *ctx, const double *fsf, const double *lsf,
+                 double lsf_rel_threshold);
+/* Data / variance / mask setup of lib/run.py:137-200.  var may be NULL (then
+ * var_scalar is the constant variance, lib/run.py:186-192); zero variances
+ * become 1e12 (lib/run.py:180); NaN voxels get data 0 and 1/var 0 (SURVEY.md
+ * appendix A); mask may be NULL (all ones). */
+int d3d_set_data(d3d_ctx *ctx, const double *data, const double *var,
+                 double var_scalar, const uint8_t *mask);
+/* Current parameter map, lib/run.py:294-314,338. */
+int d3d_set_params(d3d_ctx *ctx, const double *params);
+int d3d_get_params(d3d_ctx *ctx, double *params);
+
+/* ---- forward model ------------------------------------------------------ */
+
+/* Run.simulate_clean, lib/run.py:597-621 (masked spaxels are zero). */
+int d3d_build_clean(d3d_ctx *ctx, double *out_cube);
+/* LSF (x) FSF convolution of an arbitrary cube: convolve_1d along z of every
+ * spectrum (lib/convolution.py:89-120) then convolve2d(..., 'same') of every
+ * channel (lib/run.py:1027-1029). */
+int d3d_convolve(d3d_ctx *ctx, const double *in_cube, double *out_cube);
+/* Fused forward model of the current parameters == Run.simulate_convolved
+ * (lib/run.py:623-652) == the sim of _compute_error_in_one_step
+ * (lib/run.py:999-1029).  out_sim may be NULL (result stays in SLOT_SIM). */
+int d3d_forward(d3d_ctx *ctx, double *out_sim);
+/* err = data - forward(params), lib/run.py:334 and :525-534 / :999-1031.
+ * Stored in SLOT_ERR; out_err may be NULL. */
+int d3d_residual(d3d_ctx *ctx, double *out_err);
+/* Per-spaxel 0.5*sum_z err^2/var of SLOT_ERR (the quantity of
+ * lib/run.py:423 summed per spectrum) and its total.  Either may be NULL. */
+int d3d_chi2_map(d3d_ctx *ctx, double *out_hw, double *total);
+
+/* Device-resident variants (no host traffic; used by bench.py). */
+int d3d_upload_slot(d3d_ctx *ctx, int slot, const double *cube);
+int d3d_download_slot(d3d_ctx *ctx, int slot, double *cube);
+int d3d_convolve_slots(d3d_ctx *ctx, int src_slot, int dst_slot);
+
+/* ---- MH-within-Gibbs ---------------------------------------------------- */
+
+/* Bounds (lib/run.py:235-245), Cauchy jump amplitudes (:251-262; the Gibbs
+ * parameter's amplitude is forced to 0), a-priori variance of the amplitude
+ * (:264-265), RNG seed (the reference is unseeded), and the cadence of the
+ * from-scratch residual refresh (:525; 0 disables). */
+int d3d_mh_config(d3d_ctx *ctx, const double min_b[3], const double max_b[3],
+                  const double jump_amp[3], double gibbs_apriori_variance,
+                  uint64_t seed, int refresh_every);
+/* Parity probe: for a proposal p_new at spaxel (y,x) against the current
+ * state, out = {ar_old, ar_new, ar_old-ar_new, sum ek^2/var, sum ek*ul/var}
+ * (lib/run.py:400-426, 464-493).  Does not modify the state. */
+int d3d_window_stats(d3d_ctx *ctx, int y, int x, const double p_new[3],
+                     double out[5]);
+/* n_sweeps sweeps of the inner loop lib/run.py:367-519 over every unmasked
+ * spaxel, numbered first_sweep .. first_sweep+n_sweeps-1 (the reference's
+ * cur_iteration).  After sweep s with s % keep_one_in == 0 the parameter map
+ * is copied to chain_out[(s/keep_one_in)] ((H,W,3) each, lib/run.py:447-451)
+ * and the log acceptance ratios to dlog_out[(s/keep_one_in)] ((H,W) each,
+ * lib/run.py:428-432); either may be NULL.  *accepted (may be NULL) receives
+ * the number of accepted MH proposals (lib/run.py:440). */
+int d3d_mh_sweeps(d3d_ctx *ctx, int n_sweeps, int first_sweep, int keep_one_in,
+                  double *chain_out, double *dlog_out, int64_t *accepted);
+/* Last sweep's log acceptance ratios, (H,W). */
+int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
+
+/* ---- spatial tiling (multi-GPU halo exchange) ----------- */
+
+/* Number of unmasked spaxels of colour (cy,cx) = (y mod fh, x mod fw). */
+int d3d_colour_count(d3d_ctx *ctx, int colour, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DECONV3D_HIP_H */
