@@ -1,0 +1,267 @@
+#!/usr/bin/env python
+# coding=utf-8
+"""
+bench.py -- spaxel-updates/sec of the MH-within-Gibbs hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full sweep (every unmasked spaxel updated once: proposal,
+windowed 1/2 chi2 old/new, accept, Gibbs amplitude draw, residual write-back)
+over BASELINE config 3: a synthetic MUSE-WFM-sized 300x300x128 cube, Moffat
+11x11 FSF, MUSE-like LSF, fp64, inputs resident in HBM before the timed region.
+N > 1 runs N independent chains, one per GPU (BASELINE config 5, "weak"
+scaling, no data-path collective); `--mode tiled` runs ONE chain spatially
+tiled over the ranks with halo exchange (config 4).
+
+Prints ONE JSON line (rank 0).  Besides the contract keys it carries
+  roofline      -- the MH sweep kernel (k_mh): algorithmic bytes / launch time
+  roofline_conv -- the separable LSF (x) FSF convolution of one cube
+  cpu_baseline  -- the oracle's memory-sane numpy update loop on the host cores
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VEC_PEAK_TF = 78.6     # vector fp64 peak
+
+WORKLOADS = {
+    # name: (D, H, W, fsf size)
+    "c3_300x300x128": (128, 300, 300, 11),
+    "c2_64x64x64": (64, 64, 64, 11),
+    "c1_32x16x16": (32, 16, 16, 9),
+}
+
+
+def build_taps(D, fsf_size):
+    """Taps of SURVEY.md 8(d); formulas of lib/spread_functions.py:165-189
+    (Moffat, beta 2.5, FWHM 3 px, evaluated on an fsf_size^2 grid and fed
+    through ImageFieldSpreadFunction semantics) and a MUSE-like LSF stand-in
+    (box 1 px (x) Gaussian sigma 0.9 px)."""
+    from deconv3d_amd.spread_functions import moffat_image, muse_like_lsf_vector
+    from deconv3d_amd.spread_functions import gaussian_image, gaussian_lsf_vector_px
+    if fsf_size == 9:
+        return gaussian_image(3.0), gaussian_lsf_vector_px(D, 0.9088)
+    fsf = moffat_image((fsf_size, fsf_size), beta=2.5, fwhm_px=3.0)
+    lsf = muse_like_lsf_vector(D, sigma_px=0.9, box_px=1.0)
+    return fsf, lsf
+
+
+def synthetic_inputs(eng, D, H, W, fsf, seed, A0=10.0):
+    """SURVEY.md 8(d) synthetic cube; the noiseless model comes from the
+    (parity-tested) device forward model so that setup stays fast."""
+    rng = np.random.default_rng(seed)
+    y, x = np.indices((H, W))
+    r2 = (y - H / 2.) ** 2 + (x - W / 2.) ** 2
+    truth = np.dstack((A0 * np.exp(-r2 / (2. * (H / 6.) ** 2)),
+                       D / 2. + (D / 8.) * np.tanh((x - W / 2.) / (W / 8.)),
+                       rng.uniform(1.5, 3.0, size=(H, W))))
+    eng.set_params(truth)
+    clean = eng.forward()
+    sigma = 0.05 * A0 * np.max(fsf)
+    data = clean + rng.normal(0., sigma, size=(D, H, W))
+    var = np.full((D, H, W), sigma ** 2)
+    min_b = np.array([0., 0., 0.])
+    max_b = np.array([np.amax(data) / np.amax(fsf), D - 1., float(D)])  # lib/line_models.py:79-90
+    init = min_b + (max_b - min_b) * rng.random((H, W, 3))            # lib/run.py:310-314
+    return data, var, truth, init, min_b, max_b
+
+
+def window_voxels(H, W, fh, fw):
+    """Sum over spaxels of the clipped window area (lib/run.py:407-410)."""
+    fhh, fhw = (fh - 1) // 2, (fw - 1) // 2
+    ny = np.minimum(np.arange(H) + fhh + 1, H) - np.maximum(np.arange(H) - fhh, 0)
+    nx = np.minimum(np.arange(W) + fhw + 1, W) - np.maximum(np.arange(W) - fhw, 0)
+    return int(ny.sum()) * int(nx.sum())
+
+
+def cpu_baseline(data, var, mask, fsf, lsf, params, min_b, max_b, err, budget_s):
+    """The oracle's memory-sane numpy update loop (oracle.mh_update, i.e.
+    lib/run.py:369-519 with local windows) on a time-bounded sample of the same
+    workload.  Single python process, one core."""
+    from oracle import deconv3d_oracle as O
+    st = O.MHState.__new__(O.MHState)
+    st.data, st.var, st.mask, st.fsf, st.lsf = data, var, mask, fsf, lsf
+    st.params = np.array(params)
+    st.min_b, st.max_b = min_b, max_b
+    st.amp = np.array([0., 0.1, 0.1])
+    st.ra = float(max_b[0] ** 2)
+    st.seed = 12345
+    st.err = np.array(err)
+    st.accepted = 0
+    st.dlog = np.zeros(mask.shape)
+    n = 0
+    t0 = time.perf_counter()
+    for (y, x) in O.colour_order(mask, *fsf.shape):
+        O.mh_update(st, y, x, 1)
+        n += 1
+        if n >= 200 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return n / dt, n, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3_300x300x128", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="ensemble", choices=["ensemble", "tiled"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--conv-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    if args.mode == "tiled" and world > 1:
+        from deconv3d_amd import tiling
+        return tiling.bench_tiled(args, rank, local_rank, world, dist, torch)
+
+    from deconv3d_amd import _lib
+
+    D, H, W, fs = WORKLOADS[args.workload]
+    fsf, lsf = build_taps(D, fs)
+    eng = _lib.Engine((D, H, W), fsf.shape, device=local_rank)
+    eng.set_taps(fsf, lsf)
+    seed = 12345 + rank                                 # config 5: seeds 12345 + rank
+    data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, seed)
+    mask = np.ones((H, W))
+    eng.set_data(data, var, mask=mask)
+    eng.set_params(init)
+    ra = float(max_b[0] ** 2)                           # lib/run.py:264-265
+    eng.mh_config(min_b, max_b, 0.1, ra, seed=seed, refresh_every=1000)
+    err0 = eng.residual() if (rank == 0 and not args.no_cpu) else None
+    if err0 is None:
+        eng.residual(fetch=False)
+    n_spaxels = int(mask.sum())
+
+    def barrier():
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        eng.sync()
+
+    # ---- warmup, then EXACTLY K timed sweeps ---------------------------------
+    sweep = 1
+    if args.warmup > 0:
+        eng.mh_sweeps(args.warmup, sweep)
+        sweep += args.warmup
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    accepted = eng.mh_sweeps(args.steps, sweep)
+    dev_ms = eng.timer_stop()
+    barrier()
+    dt = time.perf_counter() - t0
+    sweep += args.steps
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_updates = args.steps * n_spaxels * world
+    value = total_updates / dt
+
+    # ---- roofline of the dominant kernel (k_mh, one launch per colour) --------
+    fh, fw = fsf.shape
+    ncol = sum(1 for c in range(fh * fw) if eng.colour_count(c) > 0)
+    bytes_per_sweep = 3 * 8 * D * window_voxels(H, W, fh, fw)     # read err, read 1/var, write err
+    launches = ncol * args.steps
+    avg_launch_us = dev_ms * 1e3 / launches
+    achieved = bytes_per_sweep / ncol / (avg_launch_us * 1e-6) / 1e9
+    roofline = {"kernel": "k_mh", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "bytes_per_launch": bytes_per_sweep // ncol,
+                "avg_launch_us": round(avg_launch_us, 2), "launches": launches}
+
+    # ---- separable convolution roofline (north_star's second target) ---------
+    eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)             # warm
+    eng.sync()
+    eng.timer_start()
+    for _ in range(args.conv_iters):
+        eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
+    conv_ms = eng.timer_stop() / max(args.conv_iters, 1)
+    conv_bytes = 2 * 8 * D * H * W                                # cube in -> cube out
+    ntaps_lsf = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
+    conv_flops = 2.0 * (fh * fw + ntaps_lsf) * D * H * W
+    conv_gbs = conv_bytes / (conv_ms * 1e-3) / 1e9
+    roofline_conv = {"kernel": "k_spectral+k_spatial", "bound": "hbm",
+                     "achieved": round(conv_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(conv_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "ms_per_conv": round(conv_ms, 4),
+                     "fp64_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                     "fp64_frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)}
+
+    out = {
+        "metric": "spaxel-updates/sec (MH-Gibbs)",
+        "value": round(value, 1),
+        "unit": "spaxel-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": args.workload, "cube": [D, H, W], "fsf": "moffat %dx%d" % (fh, fw)
+                   if fs != 9 else "gaussian 9x9",
+                   "lsf_taps": ntaps_lsf, "spaxels": n_spaxels,
+                   "parallelism": "1 chain" if world == 1 else "ensemble of %d chains" % world,
+                   "variance": "full cube"},
+        "acceptance": round(accepted / float(args.steps * n_spaxels), 4),
+        "roofline": roofline,
+        "roofline_conv": roofline_conv,
+    }
+
+    if rank == 0 and not args.no_cpu:
+        cores = len(os.sched_getaffinity(0))
+        rate, n, secs = cpu_baseline(data, var, mask, fsf, lsf, init, min_b, max_b, err0,
+                                     args.cpu_seconds)
+        out["cpu_baseline"] = {
+            "value": round(rate, 2), "unit": "spaxel-updates/s", "cores": 1, "kind": "port",
+            "sample": "%d updates of the same %s workload in %.1f s (oracle.mh_update, "
+                      "memory-sane numpy restatement of lib/run.py:369-519; the "
+                      "reference-faithful form needs an %.1f TB contributions array and "
+                      "cannot run)" % (n, args.workload, secs, H * W * D * H * W * 8 / 1e12),
+            "host_cores_visible": cores, "numpy": np.__version__}
+        out["vs_cpu"] = round(value / rate, 1)
+
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

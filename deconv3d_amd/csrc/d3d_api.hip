@@ -315,30 +315,20 @@ void pick_mh_geometry(d3d_ctx *c) {
     int nt_env = 0, mi_env = -1;
     if (const char *e = getenv("D3D_MH_NT")) nt_env = atoi(e);
     if (const char *e = getenv("D3D_MH_MAXIT")) mi_env = atoi(e);
+    // Measured on MI355X (300x300x128, 11x11): small workgroups that re-read
+    // the err window in pass 2 (MAXIT = 0) beat register-resident windows --
+    // 6 workgroups per CU overlap each other's load / reduce / store phases.
     const int cands[3] = {256, 512, 1024};
     int nt = 1024;
-    for (int k = 0; k < 3; ++k) {
-        const int G = cands[k] / c->HL;
-        if (cands[k] < need || G < 1) continue;
-        const int iters = (npos + G - 1) / G;
-        if (iters <= 8) {
+    for (int k = 0; k < 3; ++k)
+        if (cands[k] >= need && cands[k] / c->HL >= 1) {
             nt = cands[k];
             break;
         }
-    }
     if ((nt_env == 256 || nt_env == 512 || nt_env == 1024) && nt_env >= need) nt = nt_env;
     const int G = nt / c->HL;
     const int iters = (npos + G - 1) / G;
     int maxit = 0;
-    const int steps[4] = {4, 8, 16, 32};
-    for (int k = 0; k < 4; ++k)
-        if (iters <= steps[k]) {
-            maxit = steps[k];
-            break;
-        }
-    // override: 0 = re-read the window in pass 2; 4/8/16/32 accepted when they
-    // cover the window
-    if (mi_env == 0) maxit = 0;
     if ((mi_env == 4 || mi_env == 8 || mi_env == 16 || mi_env == 32) && mi_env >= iters)
         maxit = mi_env;
     c->mh_nt = nt;

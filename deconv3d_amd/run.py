@@ -1,0 +1,437 @@
+# coding=utf-8
+"""
+``Run`` -- the MCMC deconvolution runner, drop-in for the reference's
+``lib/run.py`` class ``Run`` (constructor kwargs :95-109, result attributes
+:540-549, helper methods :553-708, 742-840).
+
+The host control flow (validation, setup, stopping rule, chain bookkeeping) is
+restated here; everything inside the reference's per-spaxel loop
+(lib/run.py:367-519) and the forward models (:597-708, 999-1031) runs on the
+GPU through ``libdeconv3d_hip.so``.  There is no CPU fallback.
+
+Differences from the reference, all deliberate:
+  * additive kwargs ``seed=`` (the reference is unseeded), ``device=``,
+    ``refresh_every=`` (the reference hard-codes 1000, lib/run.py:525);
+  * spaxels are scanned colour by colour ((y mod fh, x mod fw) classes, whose
+    FSF windows are disjoint) instead of row-major -- the reference declares
+    the scan order overridable (lib/run.py:553-560);
+  * the (H,W,D,H,W) ``contributions`` array (lib/run.py:285-288) is never
+    built: a spaxel's old contribution is recomputed from its parameters;
+  * chain / likelihoods are NaN-initialised instead of uninitialised memory;
+  * the user's mask is copied, not mutated; zero variances become 1e12 for
+    ndarray input too; NaN voxels get zero weight in the Gibbs sums as well;
+  * 1-D ``initial_parameters`` are broadcast as the docstring promises.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from os.path import splitext
+
+import numpy as np
+
+from . import _lib
+from .cube import Cube, read_fits
+from .instruments import Instrument
+from .line_models import LineModel, SingleGaussianLineModel
+from .math_utils import median_clip
+
+logging.basicConfig(level=logging.INFO)
+logger = logging.getLogger('deconv3d')
+
+CIRCLE_4TH = np.pi / 2.
+
+
+class Run:
+    """
+    Main runner of the deconvolution::
+
+        cube = Cube.from_fits('my_fits.fits')
+        inst = MUSE()
+        run = Run(cube, inst, max_iterations=10000)
+        run.plot_chain()
+
+    Arguments are those of the reference (lib/run.py:51-109): ``cube``
+    (FITS path or Cube), ``instrument``, ``mask``, ``variance``, ``model``,
+    ``initial_parameters``, ``jump_amplitude``, ``gibbs_apriori_variance``,
+    ``max_iterations``, ``keep_one_in``, ``write_every``,
+    ``min_acceptance_rate``; plus ``seed``, ``device``, ``refresh_every``.
+    """
+
+    def __init__(
+        self,
+        cube,
+        instrument=None,
+        mask=None,
+        variance=None,
+        model=SingleGaussianLineModel,
+        initial_parameters=None,
+        jump_amplitude=0.1,
+        gibbs_apriori_variance=None,
+        max_iterations=100000,
+        keep_one_in=1,
+        write_every=10000,
+        min_acceptance_rate=0.01,
+        seed=12345,
+        device=0,
+        refresh_every=1000,
+        sweeps_per_call=None,
+    ):
+        # lib/run.py:112-114
+        assert keep_one_in > 0, "keep_one_in= MUST be a positive integer"
+        assert write_every > 0, "write_every= MUST be a positive integer"
+        assert max_iterations > 0, "max_iterations= MUST be a positive integer"
+        self.logger = logger
+        self.keep_one_in = int(keep_one_in)
+        self.max_iterations = int(max_iterations)
+        self.write_every = int(write_every)
+
+        # ---- input cube (lib/run.py:119-143) --------------------------------
+        if isinstance(cube, str):
+            cube = Cube.from_fits(cube)
+        if not isinstance(cube, Cube):
+            raise TypeError("Provided cube is not a HyperspectralCube")
+        if cube.is_empty():
+            raise ValueError("Provided cube is empty")
+        self.cube = cube
+        signal_max = np.nanmax(self.cube.data)
+        assert signal_max > 1e-10, \
+            "The input cube has data that is too small and will cause " \
+            "numerical instability, infinite loops, or worse : bad science."
+        cube_shape = cube.data.shape
+        cube_depth, cube_height, cube_width = cube_shape
+
+        # ---- mask (lib/run.py:151-165), copied instead of mutated -------------
+        if mask is None:
+            mask = np.ones((cube_height, cube_width))
+        if isinstance(mask, str):
+            mask, _ = read_fits(mask)
+        mask = np.array(mask, dtype=np.float64)
+        if mask.shape != (cube_height, cube_width):
+            raise ValueError("Mask MUST have (%d, %d) shape, got %s."
+                             % (cube_height, cube_width, str(mask.shape)))
+        mask[np.isnan(np.sum(self.cube.data, 0))] = 0
+        self.mask = mask
+        spaxels_count = int(np.sum(self.mask == 1))
+        cnt_iterations = int(math.ceil(max_iterations / float(keep_one_in)))
+
+        # ---- variance (lib/run.py:170-200) ---------------------------------
+        if variance is not None:
+            if isinstance(variance, str):
+                variance = Cube.from_fits(variance)
+            if isinstance(variance, Cube):
+                if variance.data is None:
+                    self.logger.warning("Provided variance cube is empty")
+                variance_cube = variance.data
+            elif isinstance(variance, np.ndarray):
+                variance_cube = variance
+            else:
+                raise TypeError("Provided variance is not a Cube")
+            variance_cube = np.where(variance_cube == 0.0, 1e12, variance_cube)
+        else:
+            sub_data = np.copy(cube.data[2:-2, 2:-4, 2:4])
+            _, clip_sigma, _ = median_clip(sub_data, 2.5)
+            if clip_sigma == 0:
+                clip_sigma = 1e-20
+            variance_cube = np.ones(cube_shape) * clip_sigma ** 2
+        if variance_cube.shape != cube_shape:
+            raise ValueError("Provided variance has not the correct shape."
+                             "Expected %s, got %s" % (str(cube_shape), str(variance_cube.shape)))
+        self.variance_cube = variance_cube
+        self.error_cube = np.sqrt(self.variance_cube)
+
+        # ---- instrument and taps (lib/run.py:202-224) ------------------------
+        if not isinstance(instrument, Instrument):
+            raise TypeError("Provided instrument is not an Instrument")
+        self.instrument = instrument
+        lsf = self.instrument.lsf.as_vector(self.cube)
+        self.lsf = None if lsf is None else np.asarray(lsf, dtype=np.float64)
+        self.fsf = np.asarray(self.instrument.fsf.as_image(self.cube), dtype=np.float64)
+        if self.fsf.ndim != 2 or self.fsf.shape[0] % 2 == 0 or self.fsf.shape[1] % 2 == 0:
+            raise ValueError("FSF *must* be of odd dimensions")
+        if self.lsf is not None and self.lsf.shape != (cube_depth,):
+            raise ValueError("LSF must have the length of the cube's spectral axis (%d), got %s"
+                             % (cube_depth, str(self.lsf.shape)))
+
+        # ---- model (lib/run.py:226-265) --------------------------------------
+        if isinstance(model, LineModel):
+            self.model = model
+        else:
+            self.model = model()
+            if not isinstance(self.model, LineModel):
+                raise TypeError("Provided model is not a LineModel")
+        self._check_model_is_on_device()
+        min_boundaries = np.array(self.model.min_boundaries(self), dtype=np.float64)
+        max_boundaries = np.array(self.model.max_boundaries(self), dtype=np.float64)
+        names = self.model.parameters()
+        self.logger.info("Min boundaries : %s" % dict(zip(names, min_boundaries)))
+        self.logger.info("Max boundaries : %s" % dict(zip(names, max_boundaries)))
+        if (min_boundaries > max_boundaries).any():
+            raise ValueError("Boundaries are inconsistent: min > max.")
+        parameters_count = len(names)
+        jumping_amplitude = np.ones(parameters_count) * np.array(jump_amplitude)
+        gpi = self.model.gibbs_parameter_index()
+        jumping_amplitude[gpi] = 0
+        if gibbs_apriori_variance is None:
+            gibbs_apriori_variance = float(max_boundaries[gpi] ** 2)
+        self.min_boundaries = min_boundaries
+        self.max_boundaries = max_boundaries
+        self.jumping_amplitude = jumping_amplitude
+        self.gibbs_apriori_variance = gibbs_apriori_variance
+        self.seed = int(seed)
+
+        # ---- chain storage (lib/run.py:267-281), NaN instead of garbage ------
+        try:
+            self.chain = np.full(
+                (cnt_iterations, cube_height, cube_width, parameters_count), np.nan)
+            likelihoods = np.full((cnt_iterations, cube_height, cube_width), np.nan)
+        except MemoryError:
+            self.logger.error("Not enough RAM available for that many iterations. "
+                              "Use a higher value in the keep_one_in= parameter.")
+            raise
+
+        # ---- initial parameters (lib/run.py:293-314) -------------------------
+        rng = np.random.default_rng(self.seed)
+        if initial_parameters is not None:
+            if isinstance(initial_parameters, str):
+                initial_parameters = np.load(initial_parameters)
+            initial_parameters = np.array(initial_parameters, dtype=np.float64)
+            if initial_parameters.ndim == 1:
+                if initial_parameters.shape[0] != parameters_count:
+                    raise ValueError("1D initial params MUST have %d values, got %d."
+                                     % (parameters_count, initial_parameters.shape[0]))
+                initial_parameters = np.tile(initial_parameters, (cube_height, cube_width, 1))
+            ip_shape = initial_parameters.shape
+            if ip_shape[0] != cube_height or ip_shape[1] != cube_width:
+                raise ValueError("Initial params MUST have (%d, %d) shape, got (%d, %d)."
+                                 % (cube_height, cube_width, ip_shape[0], ip_shape[1]))
+            self.chain[0] = initial_parameters
+        else:
+            draws = rng.random((cube_height, cube_width, parameters_count))
+            self.chain[0] = min_boundaries + (max_boundaries - min_boundaries) * draws
+
+        # ---- device context ----------------------------------------------
+        self.engine = _lib.Engine(cube_shape, self.fsf.shape, device=device)
+        self.engine.set_taps(self.fsf, self.lsf)
+        self.engine.set_data(self.cube.data, self.variance_cube, mask=self.mask)
+        self.engine.set_params(self.chain[0])
+        self.engine.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
+                              gibbs_apriori_variance, seed=self.seed,
+                              refresh_every=refresh_every)
+        self.logger.info("Iteration #1")
+        self.engine.residual(fetch=False)          # lib/run.py:317-334
+
+        # ---- MH within Gibbs loop (lib/run.py:336-537) -------------------------
+        cur_iteration = 1
+        cur_acceptance_rate = 0.
+        accepted_count = spaxels_count             # first iteration counts as accepted
+        # the reference re-evaluates the stopping rule every sweep; sweeps are
+        # batched per device call here (at most up to the next saved sweep)
+        if sweeps_per_call is None:
+            sweeps_per_call = max(1, min(int(keep_one_in), 64))
+        self.iterations_done = 1
+        while cur_iteration < max_iterations and \
+                (cur_acceptance_rate > min_acceptance_rate or cur_acceptance_rate == 0.):
+            max_accepted_count = spaxels_count * cur_iteration
+            if max_accepted_count > 0:
+                cur_acceptance_rate = float(accepted_count) / float(max_accepted_count)
+            n = min(sweeps_per_call, max_iterations - cur_iteration)
+            self.logger.info("Iteration #%d / %d, %2.0f%%" %
+                             (cur_iteration + 1, max_iterations, 100 * cur_acceptance_rate))
+            accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
+                                                    self.chain, likelihoods)
+            cur_iteration += n
+        self.iterations_done = cur_iteration
+        self.acceptance_rate = float(accepted_count) / float(max(spaxels_count * cur_iteration, 1))
+
+        # ---- outputs (lib/run.py:539-549) ------------------------------------
+        self.likelihoods = likelihoods
+        self.parameters = self.extract_parameters()
+        self.convolved_cube = Cube(data=self.simulate_convolved(cube_shape, self.parameters),
+                                   meta=self.cube.meta, x=cube.x, y=cube.y, z=cube.z)
+        self.clean_cube = Cube(data=self.simulate_clean(cube_shape, self.parameters),
+                               meta=self.cube.meta, x=cube.x, y=cube.y, z=cube.z)
+
+    # ------------------------------------------------------------------------
+
+    def _check_model_is_on_device(self):
+        """The HIP kernels evaluate SingleGaussianLineModel; subclasses may
+        change names/bounds but not the curve or the Gibbs index."""
+        m = self.model
+        ok = (isinstance(m, SingleGaussianLineModel)
+              and type(m).modelize is SingleGaussianLineModel.modelize
+              and type(m).gaussian is SingleGaussianLineModel.gaussian
+              and type(m).post_jump is LineModel.post_jump
+              and m.gibbs_parameter_index() == 0
+              and len(m.parameters()) == 3)
+        if not ok:
+            raise NotImplementedError(
+                "deconv3d_amd evaluates the line model on the GPU and implements "
+                "SingleGaussianLineModel (optionally with overridden boundaries); custom "
+                "modelize()/post_jump()/gibbs index are not supported yet.")
+
+    # ITERATORS ###############################################################
+
+    def spaxel_iterator(self):
+        """(y, x) of every unmasked spaxel, row-major (lib/run.py:553-566).
+        The device sweep visits the same set colour by colour."""
+        h, w = self.mask.shape
+        for y in range(h):
+            for x in range(w):
+                if self.mask[y, x] == 1:
+                    yield (y, x)
+
+    # MCMC ####################################################################
+
+    def jump_from(self, parameters, amplitude):
+        """Host mirror of the Cauchy proposal (lib/run.py:570-579); the device
+        draws its own from Philox."""
+        size = len(parameters)
+        u = np.random.default_rng().uniform(-CIRCLE_4TH, CIRCLE_4TH, size=size)
+        return parameters + amplitude * np.tan(u)
+
+    def extract_parameters(self, percentage=20.):
+        """Mean of the last ``percentage`` % of the saved chain
+        (lib/run.py:581-593); slots never written (early stop) are ignored."""
+        n_valid = (self.iterations_done - 1) // self.keep_one_in + 1
+        saved = self.chain[:max(1, min(n_valid, self.chain.shape[0]))]
+        s = (100. - percentage) * saved.shape[0] / 100.
+        return np.nanmean(saved[int(s):, ...], 0)
+
+    # SIMULATOR ###############################################################
+
+    def simulate_clean(self, shape, parameters):
+        """Cube of the raw lines (lib/run.py:597-621), built on the device."""
+        self._check_shape(shape)
+        self.engine.set_params(parameters)
+        return self.engine.build_clean()
+
+    def simulate_convolved(self, shape, parameters):
+        """Cube of the LSF- and FSF-convolved lines (lib/run.py:623-652), by the
+        fused device forward model."""
+        self._check_shape(shape)
+        self.engine.set_params(parameters)
+        return self.engine.forward()
+
+    def contribution_of_spaxel(self, x, y, parameters, cube_width, cube_height, cube_depth,
+                               fsf=None, lsf=None, lsf_fft=None):
+        """
+        Full-size cube holding the convolved contribution of one spaxel's line
+        (lib/run.py:654-708).  Returns ``(cube, lsf_fft)`` like the reference;
+        ``lsf_fft`` is passed through (the device does not use FFTs).  The taps
+        are the run's own.
+        """
+        self._check_shape((cube_depth, cube_height, cube_width))
+        saved = self.engine.get_params()
+        only = np.zeros_like(saved)
+        only[..., 2] = 1.0
+        only[y, x] = parameters
+        single = np.zeros((cube_height, cube_width))
+        single[y, x] = 1
+        # a map with zero amplitude everywhere else contributes nothing
+        self.engine.set_params(only)
+        out = self.engine.forward()
+        self.engine.set_params(saved)
+        return out, lsf_fft
+
+    def _check_shape(self, shape):
+        if tuple(shape) != tuple(self.cube.data.shape):
+            raise ValueError("shape %s differs from the run's cube %s"
+                             % (tuple(shape), tuple(self.cube.data.shape)))
+
+    # SAVES ###################################################################
+
+    def save(self, name, clobber=False):
+        """Write ``<name>_parameters.npy``, ``_chain.npy``, ``_matlab.mat``,
+        ``_images.png``, ``_chain.png``, ``_convolved_cube.fits``,
+        ``_clean_cube.fits``, ``_result.npz`` (lib/run.py:742-788)."""
+        self.save_parameters_npy("%s_parameters.npy" % name)
+        self.save_chain_npy("%s_chain.npy" % name)
+        try:
+            self.save_matlab("%s_matlab.mat" % name)
+        except Exception as e:  # noqa
+            self.logger.error(str(e))
+        self.plot_images("%s_images.png" % name)
+        self.plot_chain(filepath="%s_chain.png" % name)
+        self.convolved_cube.to_fits("%s_convolved_cube.fits" % name, clobber)
+        self.clean_cube.to_fits("%s_clean_cube.fits" % name, clobber)
+        np.savez("%s_result.npz" % name, chain=self.chain, likelihoods=self.likelihoods,
+                 fsf=self.fsf, lsf=self.lsf if self.lsf is not None else np.zeros(0))
+
+    def save_parameters_npy(self, filepath):
+        """lib/run.py:790-797; reusable as ``initial_parameters``."""
+        np.save(filepath, self.extract_parameters())
+
+    def save_chain_npy(self, filepath):
+        """lib/run.py:799-810."""
+        np.save(filepath, self.chain)
+
+    def save_matlab(self, filepath):
+        """lib/run.py:812-840."""
+        from scipy.io import savemat
+        savemat(filepath, dict(parameters=self.extract_parameters(), chain=self.chain))
+
+    # PLOTS ###################################################################
+
+    def plot_chain(self, x=None, y=None, filepath=None, bound=True):
+        """Chain and log acceptance ratio of one spaxel (lib/run.py:844-894)."""
+        from matplotlib import pyplot as plot
+        self._check_image_filepath(filepath)
+        if x is None:
+            x = int(math.floor(self.cube.shape[2] / 2.))
+        if y is None:
+            y = int(math.floor(self.cube.shape[1] / 2.))
+        chain_t = np.transpose(self.chain[:, y, x, :])
+        names = self.model.parameters()
+        bmin, bmax = self.min_boundaries, self.max_boundaries
+        plot.clf()
+        for i, name in enumerate(names):
+            plot.subplot2grid((2, len(names)), (0, i))
+            plot.plot(chain_t[i])
+            if bound:
+                plot.ylim(bmin[i], bmax[i])
+            plot.title(name, fontsize='small')
+        plot.subplot2grid((2, len(names)), (1, 0), colspan=len(names))
+        plot.plot(self.likelihoods[:, y, x])
+        plot.title('likelihood', fontsize='small')
+        if filepath is None:
+            plot.show()
+        else:
+            plot.savefig(filepath)
+
+    def plot_images(self, filepath=None):
+        """Mosaic of measured / convolved / FSF / clean / mask images
+        (lib/run.py:896-985)."""
+        from matplotlib import pyplot as plot
+        self._check_image_filepath(filepath)
+        p = self.extract_parameters()
+        panels = [
+            ('Measured', np.nanmean(self.cube.data, 0)),
+            ('Simulation Convolved', self.simulate_convolved(self.cube.data.shape, p).mean(0)),
+            ('FSF', self.fsf),
+            ('Simulation Clean', self.simulate_clean(self.cube.data.shape, p).mean(0)),
+            ('Mask', self.mask),
+        ]
+        fig = plot.figure(1, figsize=(16, 9))
+        plot.clf()
+        plot.subplots_adjust(wspace=0.25, hspace=0.25, bottom=0.05, top=0.95, left=0.05,
+                             right=0.95)
+        for i, (title, image) in enumerate(panels):
+            sub = fig.add_subplot(2, 3, i + 1)
+            sub.set_title(title)
+            plot.imshow(image, interpolation='nearest', origin='lower')
+            plot.xticks(fontsize=8)
+            plot.yticks(fontsize=8)
+            plot.colorbar().ax.tick_params(labelsize=8)
+        if filepath is None:
+            plot.show()
+        else:
+            plot.savefig(filepath)
+
+    def _check_image_filepath(self, filepath):
+        if filepath is not None:
+            _, extension = splitext(filepath)
+            supported = ['.png', '.pdf']
+            if extension not in supported:
+                raise ValueError("Extension '%s' is not supported, you may use one of %s"
+                                 % (extension, ', '.join(supported)))
