@@ -90,6 +90,9 @@ struct d3d_ctx {
     int refresh_every = 1000;
 
     int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
+    bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
+    int march_hy = 16;            // output rows per strip of the march kernel
+    int march_mode = 2;           // 0: tile kernel, 1: march, 2: march + x symmetry when the FSF has it
     int sp_nt = 256;              // spectral / spatial block size
 };
 
@@ -200,6 +203,31 @@ int launch_spatial_fw(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, d
     return 0;
 }
 
+template <int NT, int FS, int TX, bool SYMX, bool UNI>
+int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    const int S = NT / c->HL;
+    const int HY = c->march_hy;
+    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
+    const unsigned grid = (unsigned)((items + S - 1) / S);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI>), dim3(grid),
+                       dim3(NT), 0, c->stream, A, in, out, HY);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NT, int FS>
+int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    constexpr int TX = (FS >= 9 ? 3 : 4);
+    const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
+    const bool sym = c->march_mode == 2 && c->fsf_symx;
+    if (uni) {
+        if (sym) return launch_march<NT, FS, TX, true, true>(c, A, in, out);
+        return launch_march<NT, FS, TX, false, true>(c, A, in, out);
+    }
+    if (sym) return launch_march<NT, FS, TX, true, false>(c, A, in, out);
+    return launch_march<NT, FS, TX, false, false>(c, A, in, out);
+}
+
 template <int NT>
 int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *data) {
     d3d::SpatialArgs A;
@@ -211,6 +239,18 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.fw = c->fw;
     A.fsf = c->fsf;
     A.data = data;
+    if (c->march_mode > 0 && c->fh == c->fw) {
+        switch (c->fw) {
+            case 3: return launch_march_fs<NT, 3>(c, A, in, out);
+            case 5: return launch_march_fs<NT, 5>(c, A, in, out);
+            case 7: return launch_march_fs<NT, 7>(c, A, in, out);
+            case 9: return launch_march_fs<NT, 9>(c, A, in, out);
+            case 11: return launch_march_fs<NT, 11>(c, A, in, out);
+            case 13: return launch_march_fs<NT, 13>(c, A, in, out);
+            case 15: return launch_march_fs<NT, 15>(c, A, in, out);
+            default: break;
+        }
+    }
     switch (c->fw) {
         case 1: return launch_spatial_fw<NT, 1>(c, A, in, out);
         case 3: return launch_spatial_fw<NT, 3>(c, A, in, out);
@@ -505,6 +545,18 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->fsf, fsf, (size_t)c->fh * c->fw * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
+    c->fsf_symx = true;
+    for (int k = 0; k < c->fh && c->fsf_symx; ++k)
+        for (int i = 0; i < c->fw / 2; ++i)
+            if (fsf[k * c->fw + i] != fsf[k * c->fw + (c->fw - 1 - i)]) {
+                c->fsf_symx = false;
+                break;
+            }
+    if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
+    if (const char *e = getenv("D3D_MARCH_HY")) {
+        const int v = atoi(e);
+        if (v >= 1) c->march_hy = v;
+    }
     std::vector<int> shift;
     std::vector<double> weight;
     if (lsf) {

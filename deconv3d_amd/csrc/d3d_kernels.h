@@ -265,6 +265,144 @@ __global__ __launch_bounds__(NT) void k_spatial(SpatialArgs A, const double *__r
     }
 }
 
+// Column march (the fast path for square FSFs).  A thread owns one z-pair and
+// TX output columns and walks down HY output rows.  It keeps the FS output rows
+// that the current input row touches as a register ring: input row r feeds ring
+// slot k (output row r - FHH + k) with tap row k, slot 0 is complete after the
+// step, is stored, and the ring shifts down one slot.  Every input row is
+// loaded ONCE per strip (TX+FS-1 loads for FS*FS*TX double2 FMAs); the taps are
+// staged in LDS and read as broadcasts; all global accesses are 16 B/lane
+// contiguous along z.
+//   UNI : HL is a multiple of 64, i.e. a wavefront works on ONE strip: strip
+//         coordinates are made scalar (readfirstlane) so that every range test
+//         is a scalar branch and the steady state (all FS slots live, strip
+//         interior in x) is one branch-free block.
+//   SYMX: the FSF is mirror-symmetric in x (fsf[k][i] == fsf[k][FS-1-i], true
+//         for every Gaussian/Moffat with pa = 0): the mirrored inputs are
+//         summed once per input row and shared by all FS slots, (FS+1)/2 FMAs
+//         per tap row instead of FS.
+template <int NT, int FS, int TX, bool SYMX, bool UNI>
+__global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
+    SpatialArgs A, const double *__restrict__ in, double *__restrict__ out, int HY) {
+    constexpr int FHH = (FS - 1) / 2;
+    constexpr int NP = SYMX ? (FHH + 1) : FS;  // products per (slot, column)
+    constexpr int NR = TX + FS - 1;            // inputs per row
+    __shared__ double s_taps[FS * FS + FS];    // + one pad row for the prefetch
+    for (int i = threadIdx.x; i < FS * FS + FS; i += NT) s_taps[i] = i < FS * FS ? A.fsf[i] : 0.0;
+    __syncthreads();
+
+    const int S = NT / A.HL;
+    int s = threadIdx.x / A.HL;
+    const int zl = threadIdx.x - s * A.HL;
+    if constexpr (UNI) s = __builtin_amdgcn_readfirstlane(s);
+    const int nxs = (A.W + TX - 1) / TX;
+    const int nys = (A.H + HY - 1) / HY;
+    const long item = (long)blockIdx.x * S + s;
+    if (s >= S || item >= (long)nxs * nys) return;
+    const int ys = (int)(item / nxs);
+    const int x0 = (int)(item - (long)ys * nxs) * TX;
+    const int y0 = ys * HY;
+    const int yend = min(y0 + HY, A.H);
+    const long rowstride = (long)A.W * A.Dp;
+    const bool xin = (x0 - FHH >= 0) && (x0 + TX - 1 + FHH < A.W);
+
+    double2 ring[FS][TX];
+#pragma unroll
+    for (int k = 0; k < FS; ++k)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
+
+    for (int r = y0 - FHH; r < yend + FHH; ++r) {
+        if (r >= 0 && r < A.H) {
+            const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
+            double2 row[NR];
+            if (xin) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    row[i] = *reinterpret_cast<const double2 *>(base + (long)i * A.Dp);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int xx = x0 - FHH + i;
+                    row[i] = (xx >= 0 && xx < A.W)
+                                 ? *reinterpret_cast<const double2 *>(base + (long)i * A.Dp)
+                                 : make_double2(0.0, 0.0);
+                }
+            }
+            // Taps are re-read from LDS every step (an opaque zero keeps the
+            // compiler from hoisting FS*FS loop-invariant registers out of the
+            // row loop), one tap row ahead of the FMAs that use it.
+            int opq = 0;
+            asm volatile("" : "+v"(opq));
+            const double *taps = s_taps + opq;
+            double tcur[NP], tnxt[NP];
+#pragma unroll
+            for (int m = 0; m < NP; ++m) tcur[m] = taps[m];
+            // SYMX: P[t][m] = row[t+m] + row[t+FS-1-m] (m < FHH), centre row[t+FHH]
+            double2 P[SYMX ? TX : 1][SYMX ? NP : 1];
+            if constexpr (SYMX) {
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+#pragma unroll
+                    for (int m = 0; m < FHH; ++m) {
+                        P[t][m].x = row[t + m].x + row[t + FS - 1 - m].x;
+                        P[t][m].y = row[t + m].y + row[t + FS - 1 - m].y;
+                    }
+                    P[t][FHH] = row[t + FHH];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FS; ++k) {
+#pragma unroll
+                for (int m = 0; m < NP; ++m) tnxt[m] = taps[(k + 1) * FS + m];
+                const int oy = r - FHH + k;
+                if (oy >= y0 && oy < yend) {
+#pragma unroll
+                    for (int m = 0; m < NP; ++m) {
+                        const double tap = tcur[m];
+#pragma unroll
+                        for (int t = 0; t < TX; ++t) {
+                            double2 x;
+                            if constexpr (SYMX) {
+                                x = P[t][m];
+                            } else {
+                                x = row[t + FS - 1 - m];
+                            }
+                            ring[k][t].x = fma(tap, x.x, ring[k][t].x);
+                            ring[k][t].y = fma(tap, x.y, ring[k][t].y);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < NP; ++m) tcur[m] = tnxt[m];
+            }
+        }
+        const int oy0 = r - FHH;  // slot 0 has received its last tap row
+        if (oy0 >= y0 && oy0 < yend) {
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const int xo = x0 + t;
+                if (xo < A.W) {
+                    const long o = (long)oy0 * rowstride + (long)xo * A.Dp + 2 * zl;
+                    double2 v = ring[0][t];
+                    if (A.data) {
+                        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+                        v.x = d.x - v.x;
+                        v.y = d.y - v.y;
+                    }
+                    *reinterpret_cast<double2 *>(out + o) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FS - 1; ++k)
+#pragma unroll
+            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+    }
+}
+
 // Any-size fallback: one output z-pair per thread, loops over all taps.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_spatial_generic(SpatialArgs A,
