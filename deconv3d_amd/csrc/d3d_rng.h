@@ -39,9 +39,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[3] = c3;
 }
 
-// (0,1) double from 64 random bits: ((u >> 11) + 0.5) * 2^-53
+// (0,1) double from 64 random bits: ((u >> 12) + 0.5) * 2^-52, exact in fp64,
+// in [2^-53, 1 - 2^-53] (never 0 or 1).
 __device__ __forceinline__ double u64_to_unit(uint64_t u) {
-    return ((double)(u >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    return ((double)(u >> 12) + 0.5) * (1.0 / 4503599627370496.0);
 }
 
 // Two uniforms of block `block` of the update (spaxel, sweep).

@@ -440,8 +440,9 @@ def philox4x32_10(counter, key):
 
 
 def u64_to_unit(u):
-    """(0,1) double from 64 random bits: ((u >> 11) + 0.5) * 2**-53."""
-    return ((u >> 11) + 0.5) * (1.0 / 9007199254740992.0)
+    """(0,1) double from 64 random bits: ((u >> 12) + 0.5) * 2**-52 (exact in
+    fp64: the result lies in [2**-53, 1 - 2**-53], never 0 or 1)."""
+    return ((u >> 12) + 0.5) * (1.0 / 4503599627370496.0)
 
 
 def philox_pair(seed, spaxel, sweep, block):

@@ -1,0 +1,201 @@
+"""
+GPU tests of the drop-in Run() API and of the committed golden vectors
+(tests/golden/*.npz: produced in the build container by make_goldens.py; the
+reference itself is not available on the GPU box).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import deconv3d_amd as d3d
+from deconv3d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["c1", "odd_depth", "asym"])
+def test_device_matches_committed_golden_vectors(name):
+    g = gold("oracle_%s.npz" % name)
+    shape = g["data"].shape
+    with _lib.Engine(shape, g["fsf"].shape) as eng:
+        eng.set_taps(g["fsf"], g["lsf"])
+        eng.set_data(g["data"], g["var"], mask=g["mask"])
+        eng.set_params(g["truth"])
+        tol = 1e-12
+        assert np.max(np.abs(eng.build_clean() - g["clean"])) <= tol * np.max(np.abs(g["clean"]))
+        assert np.max(np.abs(eng.forward() - g["sim"])) <= tol * np.max(np.abs(g["sim"]))
+        eng.set_params(g["init"])
+        assert np.max(np.abs(eng.residual() - g["err"])) <= tol * np.max(np.abs(g["err"]))
+        cmap, total = eng.chi2_map()
+        np.testing.assert_allclose(cmap, g["chi2_map"], rtol=1e-10,
+                                   atol=1e-12 * g["chi2_map"].sum())
+        for rec in g["probes"]:
+            y, x = int(rec[0]), int(rec[1])
+            got = eng.window_stats(y, x, rec[2:5])
+            np.testing.assert_allclose(got[:3], rec[5:8], rtol=1e-10,
+                                       atol=1e-12 * max(rec[5], rec[6]))
+            np.testing.assert_allclose(got[3:], rec[8:], rtol=1e-10,
+                                       atol=1e-12 * max(abs(rec[8]), abs(rec[9])))
+        # deterministic chain: same Philox stream and colour order as the oracle
+        eng.mh_config(g["min_b"], g["max_b"], 0.1, float(g["ra"]), seed=int(g["chain_seed"]),
+                      refresh_every=0)
+        n = g["chain"].shape[0] - 1
+        chain = np.full((n + 1,) + g["init"].shape, np.nan)
+        dlog = np.full((n + 1,) + g["mask"].shape, np.nan)
+        acc = eng.mh_sweeps(n, 1, 1, chain, dlog)
+        live = g["mask"] == 1
+        for s in range(1, n + 1):
+            np.testing.assert_allclose(chain[s][live], g["chain"][s][live], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(dlog[s][live], g["dlog"][s - 1][live], rtol=1e-8,
+                                       atol=1e-10 * (np.max(np.abs(g["dlog"][s - 1][live])) + 1))
+        assert acc == int(g["accepted"])
+
+
+def test_reference_mat_fixture_on_device():
+    """The reference's own data set (tests/input/data14forAntoine.mat): with
+    the theoretical parameters the normalised residual of the DEVICE forward
+    model is white (std 1.000), and a short chain started there stays there."""
+    g = gold("ref_mat_fixture.npz")
+    data, var, fsf, params = g["data"], g["var"], g["fsf"], g["params"]
+    D, H, W = data.shape
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, None)
+        eng.set_data(data, var)
+        eng.set_params(params)
+        err = eng.residual()
+        z = err / np.sqrt(var)
+        assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+        cmap, total = eng.chi2_map()
+        assert abs(2 * total / data.size - 1.0) < 0.04
+
+
+def synthetic_cube(D=32, H=16, W=16, seed=12345, A0=10.0):
+    """BASELINE config 1: Gaussian FSF FWHM 3 px, Gaussian LSF
+    FWHM 2.675 A, built through the product's own plugin classes + device
+    forward model."""
+    inst = d3d.MUSE(fsf_fwhm=0.6)
+    rng = np.random.default_rng(seed)
+    y, x = np.indices((H, W))
+    r2 = (y - H / 2.) ** 2 + (x - W / 2.) ** 2
+    truth = np.dstack((A0 * np.exp(-r2 / (2. * (H / 6.) ** 2)),
+                       D / 2. + (D / 8.) * np.tanh((x - W / 2.) / (W / 8.)),
+                       rng.uniform(1.5, 3.0, size=(H, W))))
+    blank = inst.build_cube(np.ones((D, H, W)))
+    fsf, lsf = inst.fsf.as_image(blank), inst.lsf.as_vector(blank)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_params(truth)
+        clean = eng.forward()
+    sigma = 0.05 * A0 * fsf.max()
+    data = clean + rng.normal(0., sigma, size=clean.shape)
+    return inst, inst.build_cube(data), np.full(clean.shape, sigma ** 2), truth, sigma
+
+
+def test_run_end_to_end_config1():
+    """BASELINE config 1: 32x16x16, GaussianFieldSpreadFunction FWHM 3 px,
+    Gaussian LSF, SingleGaussianLineModel, 200 iterations through Run()."""
+    inst, cube, var, truth, sigma = synthetic_cube()
+    run = d3d.Run(cube, inst, variance=var, max_iterations=200, keep_one_in=2,
+                  jump_amplitude=[0., 0.5, 0.2], seed=1)
+    assert run.chain.shape == (100, 16, 16, 3) and run.likelihoods.shape == (100, 16, 16)
+    assert run.fsf.shape == (9, 9) and run.lsf.shape == (32,)
+    assert run.parameters.shape == (16, 16, 3)
+    assert run.convolved_cube.data.shape == cube.data.shape
+    assert run.clean_cube.data.shape == cube.data.shape
+    assert not np.isnan(run.chain).any()                     # every slot written
+    assert 0.0 < run.acceptance_rate <= 1.0
+    # the fit explains the data: reduced chi2 of the last sweep close to 1
+    run.engine.set_params(run.chain[-1])
+    err = run.engine.residual()
+    red = np.sum(err ** 2 / var) / err.size
+    assert red < 2.0, red
+    # bright spaxels recover their line centre to within the (3 px FWHM) blur
+    bright = truth[..., 0] > 5.0
+    assert np.median(np.abs(run.parameters[..., 1] - truth[..., 1])[bright]) < 1.5
+    # bounds respected (lib/run.py:379-388)
+    assert (run.chain[..., 0] >= 0).all() and (run.chain[..., 0] <= run.max_boundaries[0]).all()
+    assert (run.chain[..., 2] >= 0).all() and (run.chain[..., 2] <= 32).all()
+
+
+def test_run_is_reproducible_and_seed_sensitive():
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
+    a = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)
+    b = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)
+    c = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=12)
+    np.testing.assert_array_equal(a.chain, b.chain)
+    assert not np.array_equal(a.chain, c.chain)
+
+
+def test_run_initial_parameters_and_mask(tmp_path):
+    """lib/run.py:294-307 (3-D, 1-D broadcast, .npy path) and masks: masked
+    spaxels keep their parameters and contribute nothing (lib/run.py:553-566)."""
+    inst, cube, var, truth, _ = synthetic_cube(D=16, H=9, W=9, seed=5)
+    p1 = np.array([2.0, 8.0, 1.5])
+    run = d3d.Run(cube, inst, variance=var, initial_parameters=p1, max_iterations=1)
+    np.testing.assert_array_equal(run.extract_parameters(), np.tile(p1, (9, 9, 1)))
+    p3 = np.tile(p1, (9, 9, 1)) * np.linspace(0.5, 1.5, 81).reshape(9, 9, 1)
+    run = d3d.Run(cube, inst, variance=var, initial_parameters=p3, max_iterations=1)
+    np.testing.assert_array_equal(run.extract_parameters(), p3)
+    path = str(tmp_path / "p.npy")
+    np.save(path, p3)
+    run = d3d.Run(cube, inst, variance=var, initial_parameters=path, max_iterations=1)
+    np.testing.assert_array_equal(run.extract_parameters(), p3)
+    mask = d3d.above_percentile(cube, 60)
+    user_mask = mask.copy()
+    run = d3d.Run(cube, inst, variance=var, mask=mask, initial_parameters=p3, max_iterations=5)
+    np.testing.assert_array_equal(mask, user_mask)            # not mutated
+    dead = mask == 0
+    np.testing.assert_array_equal(run.chain[-1][dead], p3[dead])
+    assert not np.array_equal(run.chain[-1][~dead], p3[~dead])
+    assert np.all(run.clean_cube.data[:, dead] == 0)
+
+
+def test_run_default_variance_and_save(tmp_path):
+    """variance=None -> median-clipped sigma of the reference's sub-block
+    (lib/run.py:186-192); save() writes the reference's files (lib/run.py:742-788)."""
+    import matplotlib
+    matplotlib.use("Agg")
+    inst, cube, var, _, sigma = synthetic_cube(D=24, H=12, W=12, seed=8)
+    run = d3d.Run(cube, inst, max_iterations=4)
+    est = np.sqrt(run.variance_cube.flat[0])
+    assert np.all(run.variance_cube == run.variance_cube.flat[0]) and est > 0
+    name = str(tmp_path / "out")
+    run.save(name, clobber=True)
+    for suffix in ("_parameters.npy", "_chain.npy", "_matlab.mat", "_images.png", "_chain.png",
+                   "_convolved_cube.fits", "_clean_cube.fits", "_result.npz"):
+        assert os.path.isfile(name + suffix), suffix
+    back = d3d.Cube.from_fits(name + "_convolved_cube.fits")
+    np.testing.assert_array_equal(back.data, run.convolved_cube.data)
+    # resume from the saved parameters (lib/run.py:790-797 -> :294-307)
+    again = d3d.Run(cube, inst, initial_parameters=name + "_parameters.npy", max_iterations=1)
+    np.testing.assert_array_equal(again.extract_parameters(), run.extract_parameters())
+
+
+def test_contribution_of_spaxel_matches_forward():
+    inst, cube, var, truth, _ = synthetic_cube(D=16, H=9, W=9, seed=6)
+    run = d3d.Run(cube, inst, variance=var, max_iterations=1)
+    total = np.zeros_like(cube.data)
+    for (y, x) in [(0, 0), (4, 4), (8, 3)]:
+        c, _ = run.contribution_of_spaxel(x, y, truth[y, x], 9, 9, 16)
+        assert c.shape == cube.data.shape
+        fh = (run.fsf.shape[0] - 1) // 2
+        out = np.ones((9, 9), bool)
+        out[max(0, y - fh):y + fh + 1, max(0, x - fh):x + fh + 1] = False
+        assert np.all(c[:, out] == 0)                        # only the FSF window is touched
+        total += c
+    assert total.max() > 0
+
+
+def test_min_acceptance_rate_stops_the_loop():
+    """lib/run.py:344-350: the loop ends once the running acceptance falls
+    to min_acceptance_rate."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=7)
+    run = d3d.Run(cube, inst, variance=var, max_iterations=50, min_acceptance_rate=0.999,
+                  jump_amplitude=5.0)
+    assert run.iterations_done < 50
