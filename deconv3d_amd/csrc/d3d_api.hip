@@ -78,8 +78,10 @@ struct d3d_ctx {
     double *hwbuf = nullptr; // HW scratch (chi2 map)
     double *scal = nullptr;  // small device scalars (8 doubles)
     unsigned long long *accepted = nullptr;
-    int *spx = nullptr;  // spaxel lists per colour, concatenated
-    std::vector<int> colour_off;  // fh*fw + 1
+    int4 *spx = nullptr;  // work lists per colour (real spaxels first, then virtual ones)
+    std::vector<int> colour_off;   // fh*fw + 1: start of each colour's list
+    std::vector<int> colour_real;  // fh*fw: number of real spaxels of each colour
+    size_t spx_cap = 0;
     std::vector<uint8_t> h_mask;
 
     bool have_taps = false, have_data = false, have_params = false, have_cfg = false;
@@ -90,6 +92,12 @@ struct d3d_ctx {
     int refresh_every = 1000;
 
     int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
+    int mh_defer = 1;             // deferred residual write-back (k_mh_defer)
+    double *gbuf[2] = {nullptr, nullptr};  // pending update coefficients [slots][Dp]
+    int gpar = 0;                 // gbuf[gpar] holds the pending updates
+    int pend_cy = -1, pend_cx = -1;  // colour class of the pending updates (-1: none)
+    int slots_x = 0, slots = 0;
+    int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     int march_hy = 16;            // output rows per strip of the march kernel
     int march_mode = 2;           // 0: tile kernel, 1: march, 2: march + x symmetry when the FSF has it
@@ -281,6 +289,7 @@ int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data
 
 // params -> SLOT_TMP0 (LSF lines) -> dst (sim, or residual when resid)
 int forward_into(d3d_ctx *c, double *dst, bool resid) {
+    if (resid) c->pend_cy = c->pend_cx = -1;  // a fresh residual supersedes pending updates
     int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 1);
     if (rc) return rc;
     return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, resid ? c->slot[D3D_SLOT_DATA] : nullptr);
@@ -313,6 +322,15 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     }
     P.ra = c->ra;
     P.seed = c->seed;
+    P.gy0 = c->gy0;
+    P.gx0 = c->gx0;
+    P.Wg = c->Wg;
+    P.mask = c->mask;
+    P.Gprev = c->gbuf[c->gpar];
+    P.Gcur = c->gbuf[c->gpar ^ 1];
+    P.prev_cy = c->pend_cy;
+    P.prev_cx = c->pend_cx;
+    P.slots_x = c->slots_x;
     P.probe = 0;
     P.probe_sp = 0;
     P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
@@ -347,6 +365,43 @@ int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     }
 }
 
+template <int NT>
+int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_defer<NT>), dim3(grid), dim3(NT), lds, c->stream,
+                       P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    switch (c->mh_nt) {
+        case 256: return launch_mh_defer_nt<256>(c, P, grid, sweep);
+        case 512: return launch_mh_defer_nt<512>(c, P, grid, sweep);
+        default: return launch_mh_defer_nt<1024>(c, P, grid, sweep);
+    }
+}
+
+// Write the pending (deferred) residual updates into SLOT_ERR.
+int flush_pending(d3d_ctx *c) {
+    if (c->pend_cy < 0) return 0;
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const int NT = 256;
+    const int S = NT / c->HL > 0 ? NT / c->HL : 1;
+    if (c->HL <= 256) {
+        const unsigned grid = (unsigned)((c->HW + S - 1) / S);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
+                           c->stream, P);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)c->HW),
+                           dim3(1024), 0, c->stream, P);
+    }
+    HIP_TRY(hipGetLastError());
+    c->pend_cy = c->pend_cx = -1;
+    return 0;
+}
+
 // Choose the MH workgroup: NT threads, window kept in MAXIT double2 registers
 // per thread (0 = window re-read from memory in pass 2).
 void pick_mh_geometry(d3d_ctx *c) {
@@ -373,24 +428,42 @@ void pick_mh_geometry(d3d_ctx *c) {
         maxit = mi_env;
     c->mh_nt = nt;
     c->mh_maxit = maxit;
+    if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e) != 0;
 }
 
 int build_colour_lists(d3d_ctx *c) {
     const int ncol = c->fh * c->fw;
-    std::vector<int> list;
-    list.reserve((size_t)c->HW);
+    const int fhh = (c->fh - 1) / 2, fhw = (c->fw - 1) / 2;
+    std::vector<int4> list;
+    list.reserve(c->spx_cap);
     c->colour_off.assign(ncol + 1, 0);
+    c->colour_real.assign(ncol, 0);
     for (int cy = 0; cy < c->fh; ++cy)
         for (int cx = 0; cx < c->fw; ++cx) {
-            c->colour_off[cy * c->fw + cx] = (int)list.size();
+            const int col = cy * c->fw + cx;
+            c->colour_off[col] = (int)list.size();
+            // real spaxels: inside the cube and unmasked
             for (int y = cy; y < c->H; y += c->fh)
                 for (int x = cx; x < c->W; x += c->fw)
-                    if (c->h_mask[(size_t)y * c->W + x]) list.push_back(y * c->W + x);
+                    if (c->h_mask[(size_t)y * c->W + x]) list.push_back(make_int4(y, x, 1, 0));
+            c->colour_real[col] = (int)list.size() - c->colour_off[col];
+            // virtual positions: every other lattice point of the class whose
+            // window still intersects the cube (masked, or up to one period out)
+            for (int y = cy - c->fh; y - fhh < c->H; y += c->fh) {
+                if (y + fhh < 0) continue;
+                for (int x = cx - c->fw; x - fhw < c->W; x += c->fw) {
+                    if (x + fhw < 0) continue;
+                    const bool inside = y >= 0 && y < c->H && x >= 0 && x < c->W;
+                    if (inside && c->h_mask[(size_t)y * c->W + x]) continue;
+                    list.push_back(make_int4(y, x, 0, 0));
+                }
+            }
         }
     c->colour_off[ncol] = (int)list.size();
+    if (list.size() > c->spx_cap) return fail(D3D_ERR_HIP, "internal: colour list overflow");
     if (!list.empty())
-        HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int), hipMemcpyHostToDevice,
-                               c->stream));
+        HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int4),
+                               hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -483,7 +556,15 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->hwbuf, (size_t)c->HW * sizeof(double)));
     CTX_TRY(hipMalloc(&c->scal, 16 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->accepted, sizeof(unsigned long long)));
-    CTX_TRY(hipMalloc(&c->spx, (size_t)c->HW * sizeof(int)));
+    c->spx_cap = (size_t)(H + 2 * fh) * (W + 2 * fw);
+    CTX_TRY(hipMalloc(&c->spx, c->spx_cap * sizeof(int4)));
+    c->slots_x = (W + fw - 1) / fw;
+    c->slots = c->slots_x * ((H + fh - 1) / fh);
+    c->Wg = W;
+    for (int b = 0; b < 2; ++b) {
+        CTX_TRY(hipMalloc(&c->gbuf[b], (size_t)c->slots * c->Dp * sizeof(double)));
+        CTX_TRY(hipMemsetAsync(c->gbuf[b], 0, (size_t)c->slots * c->Dp * sizeof(double), c->stream));
+    }
     CTX_TRY(hipMemsetAsync(c->dlog, 0, (size_t)c->HW * sizeof(double), c->stream));
     CTX_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
     CTX_TRY(hipMemsetAsync(c->mask, 1, (size_t)c->HW, c->stream));
@@ -501,7 +582,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
-                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx};
+                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -586,6 +667,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_taps = true;
     c->err_valid = false;
+    c->pend_cy = c->pend_cx = -1;
     return D3D_OK;
 }
 
@@ -625,6 +707,7 @@ int d3d_set_data(d3d_ctx *c, const double *data, const double *var, double var_s
     if (rc) return rc;
     c->have_data = true;
     c->err_valid = false;
+    c->pend_cy = c->pend_cx = -1;
     return D3D_OK;
 }
 
@@ -636,6 +719,7 @@ int d3d_set_params(d3d_ctx *c, const double *params) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_params = true;
     c->err_valid = false;
+    c->pend_cy = c->pend_cx = -1;
     return D3D_OK;
 }
 
@@ -665,6 +749,8 @@ int d3d_convolve_slots(d3d_ctx *c, int src, int dst) {
     NEED(dst != D3D_SLOT_TMP1 && src != D3D_SLOT_TMP1, D3D_ERR_INVALID,
          "SLOT_TMP1 is the convolution's intermediate");
     HIP_TRY(hipSetDevice(c->device));
+    if (src == D3D_SLOT_ERR)
+        if (int rc = flush_pending(c)) return rc;
     const double *in = c->slot[src];
     if (c->ntaps > 0) {
         int rc = launch_spectral(c, in, c->slot[D3D_SLOT_TMP1]);
@@ -681,7 +767,10 @@ int d3d_upload_slot(d3d_ctx *c, int slot, const double *cube) {
     int rc = upload_cube(c, cube, c->slot[slot]);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (slot == D3D_SLOT_ERR) c->err_valid = true;
+    if (slot == D3D_SLOT_ERR) {
+        c->err_valid = true;
+        c->pend_cy = c->pend_cx = -1;
+    }
     return D3D_OK;
 }
 
@@ -689,6 +778,8 @@ int d3d_download_slot(d3d_ctx *c, int slot, double *cube) {
     NEED(c && cube, D3D_ERR_INVALID, "NULL argument");
     NEED(slot >= 0 && slot < D3D_SLOT_COUNT, D3D_ERR_INVALID, "bad slot %d", slot);
     HIP_TRY(hipSetDevice(c->device));
+    if (slot == D3D_SLOT_ERR)
+        if (int rc = flush_pending(c)) return rc;
     return download_cube(c, c->slot[slot], cube);
 }
 
@@ -727,6 +818,7 @@ int d3d_chi2_map(d3d_ctx *c, double *out_hw, double *total) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(c->have_data && c->err_valid, D3D_ERR_STATE, "residual not available");
     HIP_TRY(hipSetDevice(c->device));
+    if (int rc = flush_pending(c)) return rc;
     const unsigned grid = (unsigned)((c->HW + 3) / 4);
     hipLaunchKernelGGL(d3d::k_chi2_map, dim3(grid), dim3(256), 0, c->stream,
                        (const double *)c->slot[D3D_SLOT_ERR], (const double *)c->slot[D3D_SLOT_IVAR],
@@ -777,6 +869,7 @@ int d3d_window_stats(d3d_ctx *c, int y, int x, const double p_new[3], double out
         int rc = d3d_residual(c, nullptr);
         if (rc) return rc;
     }
+    if (int rc = flush_pending(c)) return rc;
     d3d::MHArgs P;
     fill_mh_args(c, P);
     P.probe = 1;
@@ -804,16 +897,26 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
         if (rc) return rc;
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
-    d3d::MHArgs P;
-    fill_mh_args(c, P);
     const int ncol = c->fh * c->fw;
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
         for (int col = 0; col < ncol; ++col) {
-            const int cnt = c->colour_off[col + 1] - c->colour_off[col];
-            if (cnt <= 0) continue;
+            const int n_real = c->colour_real[col];
+            if (n_real <= 0) continue;
+            d3d::MHArgs P;
+            fill_mh_args(c, P);
             P.spx = c->spx + c->colour_off[col];
-            int rc = launch_mh(c, P, (unsigned)cnt, (uint32_t)s);
-            if (rc) return rc;
+            if (c->mh_defer) {
+                // real + virtual positions: the windows of this launch tile the cube
+                const int n_all = c->colour_off[col + 1] - c->colour_off[col];
+                int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
+                if (rc) return rc;
+                c->gpar ^= 1;  // this launch's updates are now the pending ones
+                c->pend_cy = col / c->fw;
+                c->pend_cx = col % c->fw;
+            } else {
+                int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s);
+                if (rc) return rc;
+            }
         }
         if (s % keep_one_in == 0) {  // lib/run.py:353, 430-432, 449-451
             const size_t slot = (size_t)(s / keep_one_in);
@@ -851,7 +954,7 @@ int d3d_colour_count(d3d_ctx *c, int colour, int *count) {
     NEED(c && count, D3D_ERR_INVALID, "NULL argument");
     NEED(c->have_data, D3D_ERR_STATE, "data not set");
     NEED(colour >= 0 && colour < c->fh * c->fw, D3D_ERR_INVALID, "colour %d out of range", colour);
-    *count = c->colour_off[colour + 1] - c->colour_off[colour];
+    *count = c->colour_real[colour];
     return D3D_OK;
 }
 

@@ -495,9 +495,18 @@ __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long
 //   ar_old          = 1/2 sum_z C                                  (run.py:423)
 //   ar_old - ar_new = -sum_z d A - 1/2 sum_z d^2 B, d = a (E_old - E_new)  (:426)
 //   sum ek^2/var    = sum_z E^2 B,  sum ek ul/var = sum_z E (A + a E_old B) (:492-493)
-// so ONE pass over the err and 1/var windows suffices; the err window stays in
-// registers and is written back once as e + f (a E_old - r E_end)  (:508-515).
-// HBM traffic per update = read err + read ivar + write err = 3*D*fh*fw*8 B.
+// so ONE pass over the err and 1/var windows suffices, and the residual changes
+// by  err += f * G[z],  G = a E_old - r E_end                      (:508-515).
+//
+// Two write-back schemes, bit-identical in their results:
+//   k_mh        immediate: pass 2 re-reads (or keeps in registers) the err
+//               window and writes e + f G.  4 cube passes per colour.
+//   k_mh_defer  deferred: the update is NOT written; G goes to a small side
+//               buffer.  The NEXT colour's launch applies it while it streams
+//               its own windows (same-colour windows tile the cube, so every
+//               voxel has exactly one pending spaxel): each voxel is read once
+//               and written once per colour -- the algorithmic 3 passes
+//               (read err, read 1/var, write err) and no second pass.
 
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
@@ -509,10 +518,23 @@ struct MHArgs {
     const double *weight;
     double *dlog;
     unsigned long long *accepted;
-    const int *spx;  // spaxel list of this colour (global linear indices y*W+x)
+    // work list of this colour: (y, x, real, -).  real == 0 marks a VIRTUAL
+    // lattice position (outside the cube or masked) whose window intersects the
+    // cube: the deferred scheme visits it only to apply the pending updates, so
+    // that the windows of one launch tile the cube exactly.
+    const int4 *spx;
     double min_b[3], max_b[3], amp[3];
     double ra;
     uint64_t seed;
+    // tile origin inside the global cube (multi-GPU tiling): random numbers
+    // are keyed by the GLOBAL spaxel index (y+gy0)*Wg + (x+gx0).
+    int gy0, gx0, Wg;
+    // deferred write-back state
+    const uint8_t *mask;  // [H*W], 1 = spaxel is iterated
+    const double *Gprev;  // [slots][Dp] pending updates of colour prev_colour
+    double *Gcur;         // [slots][Dp] this launch's updates
+    int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
+    int slots_x;          // slot(y,x) = (y/fh)*slots_x + x/fw
     // probe mode (d3d_window_stats): evaluate probe_p at spaxel probe_sp, write
     // 5 doubles to probe_out, modify nothing.
     int probe;
@@ -523,94 +545,50 @@ struct MHArgs {
 
 __host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos) {
     const int G = NT / HL;
-    return (size_t)npos + (size_t)G * 3 * Dp + 2 * (size_t)N + Dp + 8 * (NT / 64) + 8;
+    // taps | position table (3 ints per position, as doubles) | 4 pending G rows |
+    // group partial sums | two unit lines | G | block sums
+    return (size_t)npos + 2 * (size_t)npos + 4 * (size_t)Dp + (size_t)G * 3 * Dp +
+           2 * (size_t)N + Dp + 8 * (NT / 64) + 8;
 }
 
-template <int NT, int MAXIT>
-__global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
-    extern __shared__ double smem[];
-    const int tid = threadIdx.x;
-    const int HL = P.HL, Dp = P.Dp, N = P.N, D = P.D;
+struct MHShared {
+    double *fsf, *gp, *red, *gO, *gN, *G, *sum;
+    int *pos;
+};
+
+__device__ __forceinline__ MHShared mh_carve(double *smem, int NT, int HL, int Dp, int N,
+                                              int npos) {
+    MHShared S;
     const int G = NT / HL;
-    const int g = tid / HL, zl = tid - g * HL;
-    const bool active = g < G;
-    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    S.fsf = smem;
+    S.pos = reinterpret_cast<int *>(S.fsf + npos);  // 3 ints per position
+    S.gp = S.fsf + 3 * (size_t)npos;
+    S.red = S.gp + 4 * (size_t)Dp;
+    S.gO = S.red + (size_t)G * 3 * Dp;
+    S.gN = S.gO + N;
+    S.G = S.gN + N;
+    S.sum = S.G + Dp;
+    return S;
+}
 
-    double *s_fsf = smem;
-    double *s_red = s_fsf + P.npos;
-    double *s_gO = s_red + (size_t)G * 3 * Dp;
-    double *s_gN = s_gO + N;
-    double *s_G = s_gN + N;
-    double *s_sum = s_G + Dp;
-
-    const int sp = P.probe ? P.probe_sp : P.spx[blockIdx.x];
-    const int y = sp / P.W, x = sp - y * P.W;
-
-    for (int p = tid; p < P.npos; p += NT) s_fsf[p] = P.fsf[p];
-    __syncthreads();
-
-    // ---- pass 1: window sums, err window kept in registers ----------------
-    constexpr int NREG = MAXIT > 0 ? MAXIT : 1;
-    double2 ereg[NREG];
-    double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
-    if constexpr (MAXIT > 0) {
-#pragma unroll
-        for (int it = 0; it < NREG; ++it) {
-            const int p = g + it * G;
-            const int dy = p / P.fw, dx = p - dy * P.fw;
-            const int yy = y + dy - fhh, xx = x + dx - fhw;
-            const bool ok = active && p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
-            double2 e = make_double2(0.0, 0.0), v = e;
-            double f = 0.0;
-            if (ok) {
-                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
-                e = *reinterpret_cast<const double2 *>(P.err + idx);
-                v = *reinterpret_cast<const double2 *>(P.ivar + idx);
-                f = s_fsf[p];
-            }
-            ereg[it] = e;
-            const double fvx = f * v.x, fvy = f * v.y;
-            sA.x = fma(fvx, e.x, sA.x);
-            sA.y = fma(fvy, e.y, sA.y);
-            sB.x = fma(f, fvx, sB.x);
-            sB.y = fma(f, fvy, sB.y);
-            sC.x = fma(v.x * e.x, e.x, sC.x);
-            sC.y = fma(v.y * e.y, e.y, sC.y);
-        }
-    } else {
-        if (active) {
-            for (int p = g; p < P.npos; p += G) {
-                const int dy = p / P.fw, dx = p - dy * P.fw;
-                const int yy = y + dy - fhh, xx = x + dx - fhw;
-                if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
-                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
-                const double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
-                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
-                const double f = s_fsf[p];
-                const double fvx = f * v.x, fvy = f * v.y;
-                sA.x = fma(fvx, e.x, sA.x);
-                sA.y = fma(fvy, e.y, sA.y);
-                sB.x = fma(f, fvx, sB.x);
-                sB.y = fma(f, fvy, sB.y);
-                sC.x = fma(v.x * e.x, e.x, sC.x);
-                sC.y = fma(v.y * e.y, e.y, sC.y);
-            }
-        }
-    }
-    if (active) {
-        double *r = s_red + (size_t)g * 3 * Dp + 2 * zl;
-        r[0] = sA.x;
-        r[1] = sA.y;
-        r[Dp] = sB.x;
-        r[Dp + 1] = sB.y;
-        r[2 * Dp] = sC.x;
-        r[2 * Dp + 1] = sC.y;
-    }
+// Everything after the window sums: proposal, unit lines + LSF, block sums,
+// accept, Gibbs draw.  Called by every thread of the block after the group
+// partial sums are in S.red (no barrier needed before the call).  Returns in
+// *Gz_out the residual update coefficient of channel `tid` (0 beyond D) and
+// true when the spaxel state was advanced (false in probe mode).
+template <int NT>
+__device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, int sp,
+                                          uint32_t sweep, double *Gz_out) {
+    const int tid = threadIdx.x;
+    const int Dp = P.Dp, N = P.N, D = P.D;
+    const int G = NT / P.HL;
 
     // ---- proposal (every thread computes the same numbers) ----------------
     const double a_old = P.params[(long)sp * 3 + 0];
     const double c_old = P.params[(long)sp * 3 + 1];
     const double w_old = P.params[(long)sp * 3 + 2];
+    const int ly = sp / P.W, lx = sp - ly * P.W;
+    const uint32_t gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
     double pn[3];
     double u_acc = 0.5;
     if (P.probe) {
@@ -619,8 +597,8 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
         pn[2] = P.probe_p[2];
     } else {
         // lib/run.py:570-579: p + amp * tan(U(-pi/2, pi/2))
-        const U2 u0 = philox_pair(P.seed, (uint32_t)sp, sweep, BLK_JUMP_AC);
-        const U2 u1 = philox_pair(P.seed, (uint32_t)sp, sweep, BLK_JUMP_W);
+        const U2 u0 = philox_pair(P.seed, gsp, sweep, BLK_JUMP_AC);
+        const U2 u1 = philox_pair(P.seed, gsp, sweep, BLK_JUMP_W);
         const double PI = 3.141592653589793;
         pn[0] = a_old + P.amp[0] * tan(PI * (u0.x - 0.5));
         pn[1] = c_old + P.amp[1] * tan(PI * (u0.y - 0.5));
@@ -634,8 +612,8 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
 
     // ---- unit lines of old and new (c,w), zero-extended to N ---------------
     if (tid < N) {
-        s_gO[tid] = (tid < D) ? unit_gaussian((double)tid, c_old, w_old) : 0.0;
-        s_gN[tid] = (tid < D) ? unit_gaussian((double)tid, pn[1], pn[2]) : 0.0;
+        S.gO[tid] = (tid < D) ? unit_gaussian((double)tid, c_old, w_old) : 0.0;
+        S.gN[tid] = (tid < D) ? unit_gaussian((double)tid, pn[1], pn[2]) : 0.0;
     }
     __syncthreads();
 
@@ -643,7 +621,7 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     double EO = 0.0, EN = 0.0, Az = 0.0, Bz = 0.0, Cz = 0.0;
     if (tid < D) {
         for (int gg = 0; gg < G; ++gg) {
-            const double *r = s_red + (size_t)gg * 3 * Dp + tid;
+            const double *r = S.red + (size_t)gg * 3 * Dp + tid;
             Az += r[0];
             Bz += r[Dp];
             Cz += r[2 * Dp];
@@ -652,12 +630,12 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
             for (int t = 0; t < P.ntaps; ++t) {
                 const int j = (tid + P.shift[t]) & (N - 1);
                 const double wt = P.weight[t];
-                EO = fma(wt, s_gO[j], EO);
-                EN = fma(wt, s_gN[j], EN);
+                EO = fma(wt, S.gO[j], EO);
+                EN = fma(wt, S.gN[j], EN);
             }
         } else {
-            EO = s_gO[tid];
-            EN = s_gN[tid];
+            EO = S.gO[tid];
+            EN = S.gN[tid];
         }
     }
     // the proposal keeps the amplitude unless amp[0] != 0 (never with Gibbs)
@@ -678,14 +656,14 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     const int wave = tid >> 6, nwaves = NT / 64;
     if ((tid & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) s_sum[wave * 8 + k] = sums[k];
+        for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
     }
     __syncthreads();
     double tot[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         double t = 0.0;
-        for (int wv = 0; wv < nwaves; ++wv) t += s_sum[wv * 8 + k];
+        for (int wv = 0; wv < nwaves; ++wv) t += S.sum[wv * 8 + k];
         tot[k] = t;
     }
 
@@ -700,12 +678,12 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
             P.probe_out[3] = tot[3];
             P.probe_out[4] = tot[4];
         }
-        return;
+        *Gz_out = 0.0;
+        return false;
     }
 
     // ---- MH accept (lib/run.py:435-445) ------------------------------------
     const bool accept = (log(u_acc) < delta) && !oob;
-    const double a_cur = accept ? a_new : a_old;
     const double c_end = accept ? pn[1] : c_old;
     const double w_end = accept ? pn[2] : w_old;
     const double Eend = accept ? EN : EO;
@@ -717,12 +695,11 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     const double ro = P.ra / (1.0 + P.ra * s_ee);
     const double mu = ro * s_eu;
     uint32_t blk = BLK_GIBBS;
-    const double r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, (uint32_t)sp,
-                                      sweep, &blk);
-    (void)a_cur;
+    const double r =
+        truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, gsp, sweep, &blk);
 
     // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
-    if (tid < Dp) s_G[tid] = (tid < D) ? (Lo - r * Eend) : 0.0;
+    *Gz_out = (tid < D) ? (Lo - r * Eend) : 0.0;
     if (tid == 0) {
         P.params[(long)sp * 3 + 0] = r;
         P.params[(long)sp * 3 + 1] = c_end;
@@ -730,11 +707,100 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
         P.dlog[sp] = delta;
         if (accept) atomicAdd(P.accepted, 1ULL);
     }
+    return true;
+}
+
+#define D3D_ACCUM(e, v, f)                  \
+    do {                                    \
+        const double fvx_ = (f) * (v).x;    \
+        const double fvy_ = (f) * (v).y;    \
+        sA.x = fma(fvx_, (e).x, sA.x);      \
+        sA.y = fma(fvy_, (e).y, sA.y);      \
+        sB.x = fma((f), fvx_, sB.x);        \
+        sB.y = fma((f), fvy_, sB.y);        \
+        sC.x = fma((v).x * (e).x, (e).x, sC.x); \
+        sC.y = fma((v).y * (e).y, (e).y, sC.y); \
+    } while (0)
+
+// Immediate write-back.  MAXIT > 0: the err window stays in MAXIT double2
+// registers per thread between the passes; MAXIT == 0: pass 2 re-reads it.
+template <int NT, int MAXIT>
+__global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp;
+    const int G = NT / HL;
+    const int g = tid / HL, zl = tid - g * HL;
+    const bool active = g < G;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const MHShared S = mh_carve(smem, NT, HL, Dp, P.N, P.npos);
+
+    int sp;
+    if (P.probe) {
+        sp = P.probe_sp;
+    } else {
+        const int4 ent = P.spx[blockIdx.x];
+        sp = ent.x * P.W + ent.y;
+    }
+    const int y = sp / P.W, x = sp - y * P.W;
+
+    for (int p = tid; p < P.npos; p += NT) S.fsf[p] = P.fsf[p];
+    __syncthreads();
+
+    // ---- pass 1: window sums ------------------------------------------------
+    constexpr int NREG = MAXIT > 0 ? MAXIT : 1;
+    double2 ereg[NREG];
+    double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+    if constexpr (MAXIT > 0) {
+#pragma unroll
+        for (int it = 0; it < NREG; ++it) {
+            const int p = g + it * G;
+            const int dy = p / P.fw, dx = p - dy * P.fw;
+            const int yy = y + dy - fhh, xx = x + dx - fhw;
+            const bool ok = active && p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            double2 e = make_double2(0.0, 0.0), v = e;
+            double f = 0.0;
+            if (ok) {
+                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+                e = *reinterpret_cast<const double2 *>(P.err + idx);
+                v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                f = S.fsf[p];
+            }
+            ereg[it] = e;
+            D3D_ACCUM(e, v, f);
+        }
+    } else {
+        if (active) {
+            for (int p = g; p < P.npos; p += G) {
+                const int dy = p / P.fw, dx = p - dy * P.fw;
+                const int yy = y + dy - fhh, xx = x + dx - fhw;
+                if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+                const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
+                const double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                const double f = S.fsf[p];
+                D3D_ACCUM(e, v, f);
+            }
+        }
+    }
+    if (active) {
+        double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
+        r[0] = sA.x;
+        r[1] = sA.y;
+        r[Dp] = sB.x;
+        r[Dp + 1] = sB.y;
+        r[2 * Dp] = sC.x;
+        r[2 * Dp + 1] = sC.y;
+    }
+
+    double Gt;
+    if (!mh_decide<NT>(P, S, sp, sweep, &Gt)) return;
+    if (tid < Dp) S.G[tid] = Gt;
     __syncthreads();
 
     // ---- pass 2: write the window back ------------------------------------
     if (!active) return;
-    const double2 Gz = *reinterpret_cast<const double2 *>(s_G + 2 * zl);
+    const double2 Gz = *reinterpret_cast<const double2 *>(S.G + 2 * zl);
     if constexpr (MAXIT > 0) {
 #pragma unroll
         for (int it = 0; it < NREG; ++it) {
@@ -744,7 +810,7 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
             const bool ok = p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             if (ok) {
                 const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
-                const double f = s_fsf[p];
+                const double f = S.fsf[p];
                 double2 e = ereg[it];
                 e.x = fma(f, Gz.x, e.x);
                 e.y = fma(f, Gz.y, e.y);
@@ -757,13 +823,145 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
             const int yy = y + dy - fhh, xx = x + dx - fhw;
             if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
             const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
-            const double f = s_fsf[p];
+            const double f = S.fsf[p];
             double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
             e.x = fma(f, Gz.x, e.x);
             e.y = fma(f, Gz.y, e.y);
             *reinterpret_cast<double2 *>(P.err + idx) = e;
         }
     }
+}
+
+// Spaxel of colour class (cy,cx) whose window covers coordinate q along one
+// axis (period per, half width hw), or -1 when that spaxel lies outside [0,n).
+__device__ __forceinline__ int covering_coord(int q, int c, int per, int hw, int n) {
+    int m = (q - c) % per;
+    if (m < 0) m += per;
+    int s = q - m;            // largest coordinate <= q of the class
+    if (q - s > hw) s += per;  // nearer one is above
+    return (s >= 0 && s < n) ? s : -1;
+}
+
+// Deferred write-back (see the section header).  Position table in LDS, per
+// window position p: [0] local spaxel index of the voxel column (-1 = outside
+// the cube), [1] tap index of the pending update there (-1 = none), [2] which
+// of the <= 4 staged pending G rows.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp;
+    const int G = NT / HL;
+    const int g = tid / HL, zl = tid - g * HL;
+    const bool active = g < G;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const MHShared S = mh_carve(smem, NT, HL, Dp, P.N, P.npos);
+
+    const int4 ent = P.spx[blockIdx.x];
+    const int y = ent.x, x = ent.y;  // may lie outside the cube when virtual
+    const bool real = ent.z != 0;
+    const int sp = y * P.W + x;
+    if (!real && P.prev_cy < 0) return;  // nothing pending, nothing to do
+
+    // the <= 2 x 2 pending spaxels that cover this window
+    int psy[2], psx[2];
+    if (P.prev_cy >= 0) {
+        psy[0] = covering_coord(max(y - fhh, 0), P.prev_cy, P.fh, fhh, P.H);
+        psy[1] = covering_coord(min(y + fhh, P.H - 1), P.prev_cy, P.fh, fhh, P.H);
+        psx[0] = covering_coord(max(x - fhw, 0), P.prev_cx, P.fw, fhw, P.W);
+        psx[1] = covering_coord(min(x + fhw, P.W - 1), P.prev_cx, P.fw, fhw, P.W);
+    } else {
+        psy[0] = psy[1] = psx[0] = psx[1] = -1;
+    }
+    for (int p = tid; p < P.npos; p += NT) {
+        S.fsf[p] = P.fsf[p];
+        const int dy = p / P.fw, dx = p - dy * P.fw;
+        const int yy = y + dy - fhh, xx = x + dx - fhw;
+        int vox = -1, tap = -1, sel = 0;
+        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+            vox = yy * P.W + xx;
+            if (P.prev_cy >= 0) {
+                const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
+                const int sx = covering_coord(xx, P.prev_cx, P.fw, fhw, P.W);
+                if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx]) {
+                    tap = (yy - sy + fhh) * P.fw + (xx - sx + fhw);
+                    sel = (sy == psy[0] ? 0 : 2) + (sx == psx[0] ? 0 : 1);
+                }
+            }
+        }
+        S.pos[3 * p + 0] = vox;
+        S.pos[3 * p + 1] = tap;
+        S.pos[3 * p + 2] = sel;
+    }
+    // stage the pending G rows (zeros where there is none)
+    for (int i = tid; i < 4 * Dp; i += NT) {
+        const int q = i / Dp, z = i - q * Dp;
+        const int sy = psy[q >> 1], sx = psx[q & 1];
+        double gv = 0.0;
+        if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx])
+            gv = P.Gprev[((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z];
+        S.gp[i] = gv;
+    }
+    __syncthreads();
+
+    // ---- the single pass: apply the pending update, write, accumulate ------
+    double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+    if (active) {
+#pragma unroll 4
+        for (int p = g; p < P.npos; p += G) {
+            const int vox = S.pos[3 * p + 0];
+            if (vox < 0) continue;
+            const int tap = S.pos[3 * p + 1];
+            const long idx = (long)vox * Dp + 2 * zl;
+            double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+            const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+            if (tap >= 0) {
+                const double fp = S.fsf[tap];
+                const double2 gz =
+                    *reinterpret_cast<const double2 *>(S.gp + S.pos[3 * p + 2] * Dp + 2 * zl);
+                e.x = fma(fp, gz.x, e.x);
+                e.y = fma(fp, gz.y, e.y);
+                *reinterpret_cast<double2 *>(P.err + idx) = e;
+            }
+            const double f = S.fsf[p];
+            D3D_ACCUM(e, v, f);
+        }
+        if (!real) return;
+        double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
+        r[0] = sA.x;
+        r[1] = sA.y;
+        r[Dp] = sB.x;
+        r[Dp + 1] = sB.y;
+        r[2 * Dp] = sC.x;
+        r[2 * Dp + 1] = sC.y;
+    }
+
+    if (!real) return;
+    double Gt;
+    if (!mh_decide<NT>(P, S, sp, sweep, &Gt)) return;
+    if (tid < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + tid] = Gt;
+}
+
+// Apply the pending updates of colour (prev_cy, prev_cx) to the whole residual
+// (before anything other than the next colour launch looks at it).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
+    const int S = NT / P.HL;
+    const int s = threadIdx.x / P.HL, zl = threadIdx.x - s * P.HL;
+    const long vox = (long)blockIdx.x * S + s;
+    if (s >= S || vox >= (long)P.H * P.W) return;
+    const int yy = (int)(vox / P.W), xx = (int)(vox - (long)yy * P.W);
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
+    const int sx = covering_coord(xx, P.prev_cx, P.fw, fhw, P.W);
+    if (sy < 0 || sx < 0 || !P.mask[sy * P.W + sx]) return;
+    const double fp = P.fsf[(yy - sy + fhh) * P.fw + (xx - sx + fhw)];
+    const double2 gz = *reinterpret_cast<const double2 *>(
+        P.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * P.Dp + 2 * zl);
+    double2 e = *reinterpret_cast<const double2 *>(P.err + vox * P.Dp + 2 * zl);
+    e.x = fma(fp, gz.x, e.x);
+    e.y = fma(fp, gz.y, e.y);
+    *reinterpret_cast<double2 *>(P.err + vox * P.Dp + 2 * zl) = e;
 }
 
 }  // namespace d3d

@@ -122,23 +122,29 @@ def test_mh_chain_matches_oracle_update_by_update(name):
         np.testing.assert_array_equal(chain[n_sweeps][dead], case["init"][dead])
 
 
-def test_register_and_reread_variants_agree(monkeypatch):
-    """The window-in-registers kernel and the re-read fallback are the same
-    arithmetic: bit-identical chains."""
-    case = make_case("c1")
+@pytest.mark.parametrize("name", ["c1", "odd_depth", "big_fsf", "tiny"])
+def test_write_back_schemes_are_bit_identical(monkeypatch, name):
+    """Deferred write-back (k_mh_defer: the next colour applies the pending
+    update), immediate re-read and immediate register-resident kernels are the
+    same arithmetic: bit-identical chains and residuals."""
+    case = make_case(name)
     outs = []
-    for maxit in ("0", None):
-        if maxit is None:
-            monkeypatch.delenv("D3D_MH_MAXIT", raising=False)
-        else:
-            monkeypatch.setenv("D3D_MH_MAXIT", maxit)
+    for env in ({"D3D_MH_DEFER": "1"}, {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "0"},
+                {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "8"}):   # same workgroup size: same summation order
+        for k in ("D3D_MH_DEFER", "D3D_MH_MAXIT", "D3D_MH_NT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         with engine_for(case) as eng:
             eng.set_params(case["init"])
             eng.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=5, refresh_every=0)
             eng.mh_sweeps(2, 1)
-            outs.append((eng.get_params(), eng.download_slot(2)))
-    np.testing.assert_array_equal(outs[0][0], outs[1][0])
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+            mid = eng.download_slot(2)          # flushes the pending colour
+            eng.mh_sweeps(1, 3)                 # and the chain continues consistently
+            outs.append((eng.get_params(), mid, eng.download_slot(2), eng.chi2_map()[0]))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_residual_refresh_keeps_chain_consistent():
