@@ -359,6 +359,7 @@ int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
 
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     switch (c->mh_nt) {
+        case 128: return launch_mh_nt<128>(c, P, grid, sweep);
         case 256: return launch_mh_nt<256>(c, P, grid, sweep);
         case 512: return launch_mh_nt<512>(c, P, grid, sweep);
         default: return launch_mh_nt<1024>(c, P, grid, sweep);
@@ -374,8 +375,27 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
+template <int NS, int NPW>
+int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds =
+        d3d::mh_ws_lds_doubles(NS, NPW, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, NPW>), dim3(grid), dim3(NS + 64 * NPW), lds,
+                       c->stream, P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    // wave-specialised kernel: 256 streaming threads + one prepare wavefront per
+    // 64 channels (D <= 256)
+    if (c->mh_defer == 1 && c->D <= 256 && c->HL <= 256) {
+        const int npw = (c->D + 63) / 64;
+        if (npw == 1) return launch_mh_ws<256, 1>(c, P, grid, sweep);
+        if (npw == 2) return launch_mh_ws<256, 2>(c, P, grid, sweep);
+        return launch_mh_ws<256, 4>(c, P, grid, sweep);
+    }
     switch (c->mh_nt) {
+        case 128: return launch_mh_defer_nt<128>(c, P, grid, sweep);
         case 256: return launch_mh_defer_nt<256>(c, P, grid, sweep);
         case 512: return launch_mh_defer_nt<512>(c, P, grid, sweep);
         default: return launch_mh_defer_nt<1024>(c, P, grid, sweep);
@@ -420,7 +440,8 @@ void pick_mh_geometry(d3d_ctx *c) {
             nt = cands[k];
             break;
         }
-    if ((nt_env == 256 || nt_env == 512 || nt_env == 1024) && nt_env >= need) nt = nt_env;
+    if ((nt_env == 128 || nt_env == 256 || nt_env == 512 || nt_env == 1024) && nt_env >= need)
+        nt = nt_env;
     const int G = nt / c->HL;
     const int iters = (npos + G - 1) / G;
     int maxit = 0;
@@ -428,7 +449,8 @@ void pick_mh_geometry(d3d_ctx *c) {
         maxit = mi_env;
     c->mh_nt = nt;
     c->mh_maxit = maxit;
-    if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e) != 0;
+    // 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain
+    if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
 }
 
 int build_colour_lists(d3d_ctx *c) {

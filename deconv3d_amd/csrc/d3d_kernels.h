@@ -571,107 +571,124 @@ __device__ __forceinline__ MHShared mh_carve(double *smem, int NT, int HL, int D
     return S;
 }
 
-// Everything after the window sums: proposal, unit lines + LSF, block sums,
-// accept, Gibbs draw.  Called by every thread of the block after the group
-// partial sums are in S.red (no barrier needed before the call).  Returns in
-// *Gz_out the residual update coefficient of channel `tid` (0 beyond D) and
-// true when the spaxel state was advanced (false in probe mode).
-template <int NT>
-__device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, int sp,
-                                          uint32_t sweep, double *Gz_out) {
-    const int tid = threadIdx.x;
-    const int Dp = P.Dp, N = P.N, D = P.D;
-    const int G = NT / P.HL;
+// ---- the decision, in three steps shared by every MH kernel ---------------
 
-    // ---- proposal (every thread computes the same numbers) ----------------
-    const double a_old = P.params[(long)sp * 3 + 0];
-    const double c_old = P.params[(long)sp * 3 + 1];
-    const double w_old = P.params[(long)sp * 3 + 2];
-    const int ly = sp / P.W, lx = sp - ly * P.W;
-    const uint32_t gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
+struct MHProposal {
+    double a_old, c_old, w_old;
     double pn[3];
+    double log_u;  // log of the acceptance uniform
+    bool oob;
+    uint32_t gsp;  // global spaxel index (Philox key)
+};
+
+// lib/run.py:369-388: Cauchy jump from the current parameters and bounds test.
+// Every calling thread computes the same numbers.
+__device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32_t sweep) {
+    MHProposal q;
+    q.a_old = P.params[(long)sp * 3 + 0];
+    q.c_old = P.params[(long)sp * 3 + 1];
+    q.w_old = P.params[(long)sp * 3 + 2];
+    const int ly = sp / P.W, lx = sp - ly * P.W;
+    q.gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
     double u_acc = 0.5;
     if (P.probe) {
-        pn[0] = P.probe_p[0];
-        pn[1] = P.probe_p[1];
-        pn[2] = P.probe_p[2];
+        q.pn[0] = P.probe_p[0];
+        q.pn[1] = P.probe_p[1];
+        q.pn[2] = P.probe_p[2];
     } else {
         // lib/run.py:570-579: p + amp * tan(U(-pi/2, pi/2))
-        const U2 u0 = philox_pair(P.seed, gsp, sweep, BLK_JUMP_AC);
-        const U2 u1 = philox_pair(P.seed, gsp, sweep, BLK_JUMP_W);
+        const U2 u0 = philox_pair(P.seed, q.gsp, sweep, BLK_JUMP_AC);
+        const U2 u1 = philox_pair(P.seed, q.gsp, sweep, BLK_JUMP_W);
         const double PI = 3.141592653589793;
-        pn[0] = a_old + P.amp[0] * tan(PI * (u0.x - 0.5));
-        pn[1] = c_old + P.amp[1] * tan(PI * (u0.y - 0.5));
-        pn[2] = w_old + P.amp[2] * tan(PI * (u1.x - 0.5));
+        q.pn[0] = q.a_old + P.amp[0] * tan(PI * (u0.x - 0.5));
+        q.pn[1] = q.c_old + P.amp[1] * tan(PI * (u0.y - 0.5));
+        q.pn[2] = q.w_old + P.amp[2] * tan(PI * (u1.x - 0.5));
         u_acc = u1.y;
     }
+    q.log_u = log(u_acc);
     // lib/run.py:379-384
-    bool oob = false;
+    q.oob = false;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) oob = oob || (pn[k] < P.min_b[k]) || (pn[k] > P.max_b[k]);
+    for (int k = 0; k < 3; ++k)
+        q.oob = q.oob || (q.pn[k] < P.min_b[k]) || (q.pn[k] > P.max_b[k]);
+    return q;
+}
 
-    // ---- unit lines of old and new (c,w), zero-extended to N ---------------
-    if (tid < N) {
-        S.gO[tid] = (tid < D) ? unit_gaussian((double)tid, c_old, w_old) : 0.0;
-        S.gN[tid] = (tid < D) ? unit_gaussian((double)tid, pn[1], pn[2]) : 0.0;
-    }
-    __syncthreads();
-
-    // ---- per-channel totals and LSF pass (thread t <-> channel t) ----------
-    double EO = 0.0, EN = 0.0, Az = 0.0, Bz = 0.0, Cz = 0.0;
-    if (tid < D) {
-        for (int gg = 0; gg < G; ++gg) {
-            const double *r = S.red + (size_t)gg * 3 * Dp + tid;
-            Az += r[0];
-            Bz += r[Dp];
-            Cz += r[2 * Dp];
-        }
+// LSF-convolved unit lines of channel ch from the zero-extended unit lines in
+// gO / gN (closed form of convolve_1d, lib/convolution.py:89-120).
+__device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const double *gN, int ch,
+                                       double *EO, double *EN) {
+    double eo = 0.0, en = 0.0;
+    if (ch < P.D) {
         if (P.ntaps > 0) {
             for (int t = 0; t < P.ntaps; ++t) {
-                const int j = (tid + P.shift[t]) & (N - 1);
+                const int j = (ch + P.shift[t]) & (P.N - 1);
                 const double wt = P.weight[t];
-                EO = fma(wt, S.gO[j], EO);
-                EN = fma(wt, S.gN[j], EN);
+                eo = fma(wt, gO[j], eo);
+                en = fma(wt, gN[j], en);
             }
         } else {
-            EO = S.gO[tid];
-            EN = S.gN[tid];
+            eo = gO[ch];
+            en = gN[ch];
         }
     }
-    // the proposal keeps the amplitude unless amp[0] != 0 (never with Gibbs)
-    const double a_new = pn[0];
-    const double Lo = a_old * EO;
-    const double d = Lo - a_new * EN;  // old minus new contribution per unit f
-    const double ulB = Az + Lo * Bz;   // sum_pos f v ul
-    double sums[7];
-    sums[0] = d * Az;
-    sums[1] = d * d * Bz;
-    sums[2] = Cz;
-    sums[3] = EO * EO * Bz;
-    sums[4] = EO * ulB;
-    sums[5] = EN * EN * Bz;
-    sums[6] = EN * ulB;
+    *EO = eo;
+    *EN = en;
+}
+
+// From the per-channel window sums to the new state.  ch = this thread's
+// channel (threads with ch >= D carry zeros), `first` = index of the first of
+// the nw wavefronts that call this (they are consecutive).  Contains one block
+// barrier.  Returns false in probe mode.
+__device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, const MHProposal &q,
+                                          int sp, uint32_t sweep, int ch, int G, double EO,
+                                          double EN, int first, int nw, bool caller,
+                                          double *Gz_out) {
+    const int Dp = P.Dp, D = P.D;
+    double sums[7] = {0, 0, 0, 0, 0, 0, 0};
+    const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
+    const double Lo = q.a_old * EO;
+    if (caller) {
+        double Az = 0.0, Bz = 0.0, Cz = 0.0;
+        if (ch < D) {
+            for (int gg = 0; gg < G; ++gg) {
+                const double *r = S.red + (size_t)gg * 3 * Dp + ch;
+                Az += r[0];
+                Bz += r[Dp];
+                Cz += r[2 * Dp];
+            }
+        }
+        const double d = Lo - a_new * EN;  // old minus new contribution per unit f
+        const double ulB = Az + Lo * Bz;   // sum_pos f v ul
+        sums[0] = d * Az;
+        sums[1] = d * d * Bz;
+        sums[2] = Cz;
+        sums[3] = EO * EO * Bz;
+        sums[4] = EO * ulB;
+        sums[5] = EN * EN * Bz;
+        sums[6] = EN * ulB;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) sums[k] = wave_sum(sums[k]);
-    const int wave = tid >> 6, nwaves = NT / 64;
-    if ((tid & 63) == 0) {
+        for (int k = 0; k < 7; ++k) sums[k] = wave_sum(sums[k]);
+        const int wave = (threadIdx.x >> 6) - first;
+        if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
+            for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
+        }
     }
     __syncthreads();
+    if (!caller) return false;
     double tot[7];
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
         double t = 0.0;
-        for (int wv = 0; wv < nwaves; ++wv) t += S.sum[wv * 8 + k];
+        for (int wv = 0; wv < nw; ++wv) t += S.sum[wv * 8 + k];
         tot[k] = t;
     }
-
     const double ar_old = 0.5 * tot[2];
     const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
 
     if (P.probe) {
-        if (tid == 0) {
+        if (ch == 0) {
             P.probe_out[0] = ar_old;
             P.probe_out[1] = ar_old - delta;
             P.probe_out[2] = delta;
@@ -683,9 +700,9 @@ __device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, in
     }
 
     // ---- MH accept (lib/run.py:435-445) ------------------------------------
-    const bool accept = (log(u_acc) < delta) && !oob;
-    const double c_end = accept ? pn[1] : c_old;
-    const double w_end = accept ? pn[2] : w_old;
+    const bool accept = (q.log_u < delta) && !q.oob;
+    const double c_end = accept ? q.pn[1] : q.c_old;
+    const double w_end = accept ? q.pn[2] : q.w_old;
     const double Eend = accept ? EN : EO;
     // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
     const double s_ee = accept ? tot[5] : tot[3];
@@ -696,11 +713,11 @@ __device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, in
     const double mu = ro * s_eu;
     uint32_t blk = BLK_GIBBS;
     const double r =
-        truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, gsp, sweep, &blk);
+        truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep, &blk);
 
     // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
-    *Gz_out = (tid < D) ? (Lo - r * Eend) : 0.0;
-    if (tid == 0) {
+    *Gz_out = (ch < D) ? (Lo - r * Eend) : 0.0;
+    if (ch == 0) {
         P.params[(long)sp * 3 + 0] = r;
         P.params[(long)sp * 3 + 1] = c_end;
         P.params[(long)sp * 3 + 2] = w_end;
@@ -708,6 +725,24 @@ __device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, in
         if (accept) atomicAdd(P.accepted, 1ULL);
     }
     return true;
+}
+
+// The whole decision with every thread of an NT-thread block taking part
+// (thread t <-> channel t); group partial sums must be in S.red (no barrier
+// needed before the call).
+template <int NT>
+__device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, int sp,
+                                          uint32_t sweep, double *Gz_out) {
+    const int tid = threadIdx.x;
+    const MHProposal q = mh_propose(P, sp, sweep);
+    if (tid < P.N) {
+        S.gO[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.c_old, q.w_old) : 0.0;
+        S.gN[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.pn[1], q.pn[2]) : 0.0;
+    }
+    __syncthreads();
+    double EO, EN;
+    mh_lsf(P, S.gO, S.gN, tid, &EO, &EN);
+    return mh_finish(P, S, q, sp, sweep, tid, NT / P.HL, EO, EN, 0, NT / 64, true, Gz_out);
 }
 
 #define D3D_ACCUM(e, v, f)                  \
@@ -940,6 +975,132 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
     double Gt;
     if (!mh_decide<NT>(P, S, sp, sweep, &Gt)) return;
     if (tid < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + tid] = Gt;
+}
+
+// Wave-specialised deferred kernel: NS streaming threads run the window pass
+// while NPW extra wavefronts (thread <-> channel) compute everything of the
+// decision that does not depend on the window -- proposal (Philox, tan), both
+// unit lines (exp) and their LSF convolution -- so that only the short tail
+// (sums -> accept -> truncated normal) follows the pass.  Each prepare
+// wavefront builds the zero-extended unit lines in its own LDS region
+// (wave-private: no block barrier while the others stream).  Same arithmetic,
+// same summation order, bit-identical results as k_mh_defer.
+__host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int NPW, int HL, int Dp, int N,
+                                                    int npos) {
+    return mh_lds_doubles(NS, HL, Dp, N, npos) + (size_t)NPW * 2 * N;
+}
+
+template <int NS, int NPW>
+__global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    constexpr int NT = NS + 64 * NPW;
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp, N = P.N;
+    const int G = NS / HL;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const MHShared S = mh_carve(smem, NS, HL, Dp, N, P.npos);
+    double *priv = S.sum + 8 * (NS / 64) + 8;
+
+    const int4 ent = P.spx[blockIdx.x];
+    const int y = ent.x, x = ent.y;  // may lie outside the cube when virtual
+    const bool real = ent.z != 0;
+    const int sp = y * P.W + x;
+    if (!real && P.prev_cy < 0) return;
+
+    int psy[2], psx[2];
+    if (P.prev_cy >= 0) {
+        psy[0] = covering_coord(max(y - fhh, 0), P.prev_cy, P.fh, fhh, P.H);
+        psy[1] = covering_coord(min(y + fhh, P.H - 1), P.prev_cy, P.fh, fhh, P.H);
+        psx[0] = covering_coord(max(x - fhw, 0), P.prev_cx, P.fw, fhw, P.W);
+        psx[1] = covering_coord(min(x + fhw, P.W - 1), P.prev_cx, P.fw, fhw, P.W);
+    } else {
+        psy[0] = psy[1] = psx[0] = psx[1] = -1;
+    }
+    for (int p = tid; p < P.npos; p += NT) {
+        S.fsf[p] = P.fsf[p];
+        const int dy = p / P.fw, dx = p - dy * P.fw;
+        const int yy = y + dy - fhh, xx = x + dx - fhw;
+        int vox = -1, tap = -1, sel = 0;
+        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+            vox = yy * P.W + xx;
+            if (P.prev_cy >= 0) {
+                const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
+                const int sx = covering_coord(xx, P.prev_cx, P.fw, fhw, P.W);
+                if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx]) {
+                    tap = (yy - sy + fhh) * P.fw + (xx - sx + fhw);
+                    sel = (sy == psy[0] ? 0 : 2) + (sx == psx[0] ? 0 : 1);
+                }
+            }
+        }
+        S.pos[3 * p + 0] = vox;
+        S.pos[3 * p + 1] = tap;
+        S.pos[3 * p + 2] = sel;
+    }
+    for (int i = tid; i < 4 * Dp; i += NT) {
+        const int q = i / Dp, z = i - q * Dp;
+        const int sy = psy[q >> 1], sx = psx[q & 1];
+        double gv = 0.0;
+        if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx])
+            gv = P.Gprev[((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z];
+        S.gp[i] = gv;
+    }
+    __syncthreads();
+
+    const bool streamer = tid < NS;
+    MHProposal q = {};
+    double EO = 0.0, EN = 0.0;
+    int ch = 0;
+    if (streamer) {
+        const int g = tid / HL, zl = tid - g * HL;
+        if (g < G) {
+            double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+#pragma unroll 4
+            for (int p = g; p < P.npos; p += G) {
+                const int vox = S.pos[3 * p + 0];
+                if (vox < 0) continue;
+                const int tap = S.pos[3 * p + 1];
+                const long idx = (long)vox * Dp + 2 * zl;
+                double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                if (tap >= 0) {
+                    const double fp = S.fsf[tap];
+                    const double2 gz = *reinterpret_cast<const double2 *>(
+                        S.gp + S.pos[3 * p + 2] * Dp + 2 * zl);
+                    e.x = fma(fp, gz.x, e.x);
+                    e.y = fma(fp, gz.y, e.y);
+                    *reinterpret_cast<double2 *>(P.err + idx) = e;
+                }
+                const double f = S.fsf[p];
+                D3D_ACCUM(e, v, f);
+            }
+            if (real) {
+                double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
+                r[0] = sA.x;
+                r[1] = sA.y;
+                r[Dp] = sB.x;
+                r[Dp + 1] = sB.y;
+                r[2 * Dp] = sC.x;
+                r[2 * Dp + 1] = sC.y;
+            }
+        }
+    } else if (real) {
+        const int pw = (tid - NS) >> 6, lane = tid & 63;
+        ch = tid - NS;
+        q = mh_propose(P, sp, sweep);
+        double *gO = priv + (size_t)pw * 2 * N;
+        double *gN = gO + N;
+        for (int j = lane; j < N; j += 64) {
+            gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
+            gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();  // wave-private region: LDS is in order per wave
+        mh_lsf(P, gO, gN, ch, &EO, &EN);
+    }
+    if (!real) return;
+    __syncthreads();  // group partial sums are in S.red
+    double Gt;
+    if (!mh_finish(P, S, q, sp, sweep, ch, G, EO, EN, NS / 64, NPW, !streamer, &Gt)) return;
+    if (ch < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + ch] = Gt;
 }
 
 // Apply the pending updates of colour (prev_cy, prev_cx) to the whole residual
