@@ -121,6 +121,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--conv-iters", type=int, default=50)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the barrier / MAX-reduce (gloo: rehearsal "
+                         "of the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -134,8 +137,14 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+            local_rank = local_rank % max(ndev, 1)
+            torch.cuda.set_device(local_rank)
 
     if args.mode == "tiled" and world > 1:
         from deconv3d_amd import tiling
@@ -181,7 +190,8 @@ def main():
     sweep += args.steps
 
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

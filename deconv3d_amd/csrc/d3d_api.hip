@@ -99,6 +99,9 @@ struct d3d_ctx {
     int slots_x = 0, slots = 0;
     int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
+    double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
+    bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
+    int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
     int march_mode = 2;           // 0: tile kernel, 1: march, 2: march + x symmetry when the FSF has it
     int sp_nt = 256;              // spectral / spatial block size
@@ -211,33 +214,54 @@ int launch_spatial_fw(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, d
     return 0;
 }
 
-template <int NT, int FS, int TX, bool SYMX, bool UNI>
+template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE>
 int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     const int S = NT / c->HL;
     const int HY = c->march_hy;
     const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
     const unsigned grid = (unsigned)((items + S - 1) / S);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI>), dim3(grid),
-                       dim3(NT), 0, c->stream, A, in, out, HY);
+    const size_t lds =
+        FUSE ? (size_t)S * TX * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double) : 0;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI, FUSE>),
+                       dim3(grid), dim3(NT), lds, c->stream, A, in, out, HY);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int NT, int FS>
+template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool sym = c->march_mode == 2 && c->fsf_symx;
     if (uni) {
-        if (sym) return launch_march<NT, FS, TX, true, true>(c, A, in, out);
-        return launch_march<NT, FS, TX, false, true>(c, A, in, out);
+        if (sym) return launch_march<NT, FS, TX, true, true, FUSE>(c, A, in, out);
+        return launch_march<NT, FS, TX, false, true, FUSE>(c, A, in, out);
     }
-    if (sym) return launch_march<NT, FS, TX, true, false>(c, A, in, out);
-    return launch_march<NT, FS, TX, false, false>(c, A, in, out);
+    if (sym) return launch_march<NT, FS, TX, true, false, FUSE>(c, A, in, out);
+    return launch_march<NT, FS, TX, false, false, FUSE>(c, A, in, out);
+}
+
+template <int NT, bool FUSE>
+int launch_march_any(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out,
+                     bool *done) {
+    *done = true;
+    switch (c->fw) {
+        case 3: return launch_march_fs<NT, 3, FUSE>(c, A, in, out);
+        case 5: return launch_march_fs<NT, 5, FUSE>(c, A, in, out);
+        case 7: return launch_march_fs<NT, 7, FUSE>(c, A, in, out);
+        case 9: return launch_march_fs<NT, 9, FUSE>(c, A, in, out);
+        case 11: return launch_march_fs<NT, 11, FUSE>(c, A, in, out);
+        case 13: return launch_march_fs<NT, 13, FUSE>(c, A, in, out);
+        case 15: return launch_march_fs<NT, 15, FUSE>(c, A, in, out);
+        default: break;
+    }
+    *done = false;
+    return 0;
 }
 
 template <int NT>
-int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *data) {
+int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *data,
+                      bool fuse_lsf) {
     d3d::SpatialArgs A;
     A.Dp = c->Dp;
     A.HL = c->HL;
@@ -247,18 +271,20 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.fw = c->fw;
     A.fsf = c->fsf;
     A.data = data;
+    A.lsf_dense = nullptr;
     if (c->march_mode > 0 && c->fh == c->fw) {
-        switch (c->fw) {
-            case 3: return launch_march_fs<NT, 3>(c, A, in, out);
-            case 5: return launch_march_fs<NT, 5>(c, A, in, out);
-            case 7: return launch_march_fs<NT, 7>(c, A, in, out);
-            case 9: return launch_march_fs<NT, 9>(c, A, in, out);
-            case 11: return launch_march_fs<NT, 11>(c, A, in, out);
-            case 13: return launch_march_fs<NT, 13>(c, A, in, out);
-            case 15: return launch_march_fs<NT, 15>(c, A, in, out);
-            default: break;
+        bool done = false;
+        int rc;
+        if (fuse_lsf) {
+            A.lsf_dense = c->lsf_dense;
+            rc = launch_march_any<NT, true>(c, A, in, out, &done);
+        } else {
+            rc = launch_march_any<NT, false>(c, A, in, out, &done);
         }
+        if (done) return rc;
+        A.lsf_dense = nullptr;
     }
+    if (fuse_lsf) return fail(D3D_ERR_STATE, "internal: fused LSF requested without march kernel");
     switch (c->fw) {
         case 1: return launch_spatial_fw<NT, 1>(c, A, in, out);
         case 3: return launch_spatial_fw<NT, 3>(c, A, in, out);
@@ -278,12 +304,23 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     return 0;
 }
 
+// True when the spatial pass can apply the LSF itself (fused epilogue).
+bool can_fuse_lsf(const d3d_ctx *c) {
+    if (!c->fuse_lsf || !c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
+    switch (c->fw) {
+        case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;
+        default: return false;
+    }
+}
+
 // out = FSF (*) in, or data - FSF (*) in when data != NULL.  in != out.
-int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data) {
+// fuse_lsf: also apply the LSF along z (only when can_fuse_lsf()).
+int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
+                   bool fuse_lsf = false) {
     switch (pick_nt(c->HL)) {
-        case 256: return launch_spatial_nt<256>(c, in, out, data);
-        case 512: return launch_spatial_nt<512>(c, in, out, data);
-        default: return launch_spatial_nt<1024>(c, in, out, data);
+        case 256: return launch_spatial_nt<256>(c, in, out, data, fuse_lsf);
+        case 512: return launch_spatial_nt<512>(c, in, out, data, fuse_lsf);
+        default: return launch_spatial_nt<1024>(c, in, out, data, fuse_lsf);
     }
 }
 
@@ -574,6 +611,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_shift, (size_t)c->N * sizeof(int)));
     CTX_TRY(hipMalloc(&c->lsf_weight, (size_t)c->N * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->lsf_dense, (2 * d3d::LSF_RL + 1) * sizeof(double)));
     CTX_TRY(hipMalloc(&c->dlog, (size_t)c->HW * sizeof(double)));
     CTX_TRY(hipMalloc(&c->hwbuf, (size_t)c->HW * sizeof(double)));
     CTX_TRY(hipMalloc(&c->scal, 16 * sizeof(double)));
@@ -604,7 +642,8 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
-                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1]};
+                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1],
+                    c->lsf_dense};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -680,6 +719,27 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
         NEED(!shift.empty(), D3D_ERR_INVALID, "LSF has no non-zero tap");
     }
     c->ntaps = (int)shift.size();
+    // dense form for the fused epilogue: out[k] = sum_j wl[j] v[(k + j - RL) mod N]
+    c->lsf_fusable = false;
+    if (const char *e = getenv("D3D_FUSE_LSF")) c->fuse_lsf = atoi(e);
+    if (c->ntaps && c->N == c->Dp && c->Dp >= 4 * d3d::LSF_RL && c->HL <= 64 && 64 % c->HL == 0) {
+        std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
+        bool ok = true;
+        for (size_t t = 0; t < shift.size(); ++t) {
+            int sg = shift[t] > c->N / 2 ? shift[t] - c->N : shift[t];
+            if (sg < -d3d::LSF_RL || sg > d3d::LSF_RL) {
+                ok = false;
+                break;
+            }
+            dense[sg + d3d::LSF_RL] += weight[t];
+        }
+        if (ok) {
+            HIP_TRY(hipMemcpyAsync(c->lsf_dense, dense.data(), dense.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->lsf_fusable = true;
+        }
+    }
     if (c->ntaps) {
         HIP_TRY(hipMemcpyAsync(c->lsf_shift, shift.data(), shift.size() * sizeof(int),
                                hipMemcpyHostToDevice, c->stream));
@@ -775,6 +835,9 @@ int d3d_convolve_slots(d3d_ctx *c, int src, int dst) {
         if (int rc = flush_pending(c)) return rc;
     const double *in = c->slot[src];
     if (c->ntaps > 0) {
+        // FSF and LSF act on different axes and commute: when possible the LSF is
+        // applied in the spatial kernel's epilogue (one pass over the cube)
+        if (can_fuse_lsf(c)) return launch_spatial(c, in, c->slot[dst], nullptr, true);
         int rc = launch_spectral(c, in, c->slot[D3D_SLOT_TMP1]);
         if (rc) return rc;
         in = c->slot[D3D_SLOT_TMP1];

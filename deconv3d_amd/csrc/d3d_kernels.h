@@ -200,10 +200,16 @@ __global__ __launch_bounds__(NT) void k_spectral(SpectralArgs A, const double *_
 //   out[Y,X] = sum_{j,i} fsf[j,i] * in[Y - j + fhh, X - i + fhw]              //
 // ------------------------------------------------------------------------- //
 
+constexpr int LSF_RL = 8;  // radius of the LSF taps the fused epilogue handles
+
 struct SpatialArgs {
     int Dp, HL, H, W, fh, fw;
     const double *fsf;   // [fh*fw]
     const double *data;  // residual epilogue: out = data - conv (or NULL)
+    // fused spectral epilogue of the march kernel (or NULL): dense LSF weights
+    // wl[j], j = 0..2*LSF_RL, so that out[k] = sum_j wl[j] * v[(k + j - LSF_RL) mod Dp]
+    // (closed form of convolve_1d for power-of-two depths, lib/convolution.py:89-120)
+    const double *lsf_dense;
 };
 
 // Register-tiled: a thread owns one z-pair and TX consecutive x outputs of one
@@ -281,13 +287,16 @@ __global__ __launch_bounds__(NT) void k_spatial(SpatialArgs A, const double *__r
 //         for every Gaussian/Moffat with pa = 0): the mirrored inputs are
 //         summed once per input row and shared by all FS slots, (FS+1)/2 FMAs
 //         per tap row instead of FS.
-template <int NT, int FS, int TX, bool SYMX, bool UNI>
+template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE>
 __global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
     SpatialArgs A, const double *__restrict__ in, double *__restrict__ out, int HY) {
     constexpr int FHH = (FS - 1) / 2;
     constexpr int NP = SYMX ? (FHH + 1) : FS;  // products per (slot, column)
     constexpr int NR = TX + FS - 1;            // inputs per row
     __shared__ double s_taps[FS * FS + FS];    // + one pad row for the prefetch
+    // fused LSF epilogue: one private spectrum buffer (with circular halo) per
+    // strip and output column; a strip never straddles wavefronts when FUSE
+    extern __shared__ double s_spec[];
     for (int i = threadIdx.x; i < FS * FS + FS; i += NT) s_taps[i] = i < FS * FS ? A.fsf[i] : 0.0;
     __syncthreads();
 
@@ -379,6 +388,45 @@ __global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
         }
         const int oy0 = r - FHH;  // slot 0 has received its last tap row
         if (oy0 >= y0 && oy0 < yend) {
+            if constexpr (FUSE) {
+                // Spectral (LSF) pass on the finished row before it is stored:
+                // FSF and LSF act on different axes and commute.  The strip's
+                // Dp-channel spectrum goes to a wave-private LDS buffer with a
+                // circular halo of LSF_RL channels; each lane reads its aligned
+                // window of 2*LSF_RL+2 channels back and applies the taps.
+                constexpr int RL = LSF_RL;
+                const int N = A.Dp;
+                double *buf = s_spec + (size_t)s * TX * (N + 2 * RL);
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    double *bt = buf + t * (N + 2 * RL);
+                    const double2 v = ring[0][t];
+                    *reinterpret_cast<double2 *>(bt + RL + 2 * zl) = v;
+                    if (2 * zl < RL) *reinterpret_cast<double2 *>(bt + N + RL + 2 * zl) = v;
+                    if (2 * zl >= N - RL) *reinterpret_cast<double2 *>(bt + RL + 2 * zl - N) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    const double *bt = buf + t * (N + 2 * RL) + 2 * zl;
+                    double w[2 * RL + 2];
+#pragma unroll
+                    for (int j = 0; j < RL + 1; ++j) {
+                        const double2 p = *reinterpret_cast<const double2 *>(bt + 2 * j);
+                        w[2 * j] = p.x;
+                        w[2 * j + 1] = p.y;
+                    }
+                    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+                    for (int j = 0; j < 2 * RL + 1; ++j) {
+                        const double wl = A.lsf_dense[j];
+                        acc.x = fma(wl, w[j], acc.x);
+                        acc.y = fma(wl, w[j + 1], acc.y);
+                    }
+                    ring[0][t] = acc;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
 #pragma unroll
             for (int t = 0; t < TX; ++t) {
                 const int xo = x0 + t;
