@@ -26,6 +26,7 @@ SYMBOLS = [
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
     "d3d_convolve_slots", "d3d_mh_config", "d3d_window_stats",
     "d3d_mh_sweeps", "d3d_get_dlog", "d3d_colour_count",
+    "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
 
 SLOT_DATA, SLOT_IVAR, SLOT_ERR, SLOT_SIM, SLOT_TMP0, SLOT_TMP1 = range(6)
@@ -90,6 +91,10 @@ def load():
                                   dbl_p, C.POINTER(C.c_int64)]
     lib.d3d_get_dlog.argtypes = [ctx_p, dbl_p]
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
+    lib.d3d_set_tile.argtypes = [ctx_p] + [C.c_int] * 7
+    lib.d3d_mh_colour.argtypes = [ctx_p, C.c_int, C.c_int]
+    lib.d3d_export_updates.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int), dbl_p]
+    lib.d3d_apply_updates.argtypes = [ctx_p, C.c_int, dbl_p]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if name not in ("d3d_version", "d3d_last_error"):
@@ -298,3 +303,28 @@ class Engine(object):
         n = C.c_int(0)
         _check(self._lib.d3d_colour_count(self._ctx, int(colour), C.byref(n)))
         return n.value
+
+    # -- spatial tiling (deconv3d_amd/tiling.py) ----------------------------
+    def set_tile(self, gy0, gx0, Wg, oy0, oy1, ox0, ox1):
+        _check(self._lib.d3d_set_tile(self._ctx, int(gy0), int(gx0), int(Wg), int(oy0),
+                                      int(oy1), int(ox0), int(ox1)))
+
+    def mh_colour(self, colour, sweep):
+        _check(self._lib.d3d_mh_colour(self._ctx, int(colour), int(sweep)))
+
+    def export_updates(self, spaxels):
+        """[n,8] records {global y, global x, a,c,w before, a,c,w after} of the
+        last update of the given local spaxel indices (y*W+x)."""
+        spaxels = np.ascontiguousarray(spaxels, dtype=np.int32)
+        out = np.empty((spaxels.shape[0], 8), dtype=np.float64)
+        if spaxels.shape[0]:
+            _check(self._lib.d3d_export_updates(
+                self._ctx, spaxels.shape[0],
+                spaxels.ctypes.data_as(C.POINTER(C.c_int)), _dp(out)))
+        return out
+
+    def apply_updates(self, records):
+        """Replay records whose first two columns are LOCAL coordinates."""
+        records = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 8)
+        if records.shape[0]:
+            _check(self._lib.d3d_apply_updates(self._ctx, records.shape[0], _dp(records)))

@@ -98,6 +98,11 @@ struct d3d_ctx {
     int pend_cy = -1, pend_cx = -1;  // colour class of the pending updates (-1: none)
     int slots_x = 0, slots = 0;
     int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
+    bool tiled = false;              // d3d_set_tile was called
+    int oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;  // owned local rectangle
+    double *prev = nullptr;          // [HW*3] parameters before each spaxel's last update
+    double *recbuf = nullptr;        // [HW*8] staging of update records
+    int *idxbuf = nullptr;           // [HW] staging of spaxel lists
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
@@ -346,6 +351,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.err = c->slot[D3D_SLOT_ERR];
     P.ivar = c->slot[D3D_SLOT_IVAR];
     P.params = c->params;
+    P.prev = c->prev;
     P.fsf = c->fsf;
     P.shift = c->lsf_shift;
     P.weight = c->lsf_weight;
@@ -497,20 +503,26 @@ int build_colour_lists(d3d_ctx *c) {
     list.reserve(c->spx_cap);
     c->colour_off.assign(ncol + 1, 0);
     c->colour_real.assign(ncol, 0);
+    // colour classes are GLOBAL: (cy,cx) = ((y+gy0) mod fh, (x+gx0) mod fw)
     for (int cy = 0; cy < c->fh; ++cy)
         for (int cx = 0; cx < c->fw; ++cx) {
             const int col = cy * c->fw + cx;
+            const int ly = ((cy - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
+            const int lx = ((cx - c->gx0) % c->fw + c->fw) % c->fw;
             c->colour_off[col] = (int)list.size();
-            // real spaxels: inside the cube and unmasked
-            for (int y = cy; y < c->H; y += c->fh)
-                for (int x = cx; x < c->W; x += c->fw)
-                    if (c->h_mask[(size_t)y * c->W + x]) list.push_back(make_int4(y, x, 1, 0));
+            // real spaxels: inside the cube, owned by this tile and unmasked
+            for (int y = ly; y < c->H; y += c->fh)
+                for (int x = lx; x < c->W; x += c->fw)
+                    if (y >= c->oy0 && y < c->oy1 && x >= c->ox0 && x < c->ox1 &&
+                        c->h_mask[(size_t)y * c->W + x])
+                        list.push_back(make_int4(y, x, 1, 0));
             c->colour_real[col] = (int)list.size() - c->colour_off[col];
+            if (c->tiled) continue;  // tiles use the immediate scheme: no virtual positions
             // virtual positions: every other lattice point of the class whose
             // window still intersects the cube (masked, or up to one period out)
-            for (int y = cy - c->fh; y - fhh < c->H; y += c->fh) {
+            for (int y = ly - c->fh; y - fhh < c->H; y += c->fh) {
                 if (y + fhh < 0) continue;
-                for (int x = cx - c->fw; x - fhw < c->W; x += c->fw) {
+                for (int x = lx - c->fw; x - fhw < c->W; x += c->fw) {
                     if (x + fhw < 0) continue;
                     const bool inside = y >= 0 && y < c->H && x >= 0 && x < c->W;
                     if (inside && c->h_mask[(size_t)y * c->W + x]) continue;
@@ -621,6 +633,11 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     c->slots_x = (W + fw - 1) / fw;
     c->slots = c->slots_x * ((H + fh - 1) / fh);
     c->Wg = W;
+    c->oy1 = H;
+    c->ox1 = W;
+    CTX_TRY(hipMalloc(&c->prev, (size_t)c->HW * 3 * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->recbuf, (size_t)c->HW * 8 * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->idxbuf, (size_t)c->HW * sizeof(int)));
     for (int b = 0; b < 2; ++b) {
         CTX_TRY(hipMalloc(&c->gbuf[b], (size_t)c->slots * c->Dp * sizeof(double)));
         CTX_TRY(hipMemsetAsync(c->gbuf[b], 0, (size_t)c->slots * c->Dp * sizeof(double), c->stream));
@@ -643,7 +660,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1],
-                    c->lsf_dense};
+                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -990,14 +1007,14 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
             d3d::MHArgs P;
             fill_mh_args(c, P);
             P.spx = c->spx + c->colour_off[col];
-            if (c->mh_defer) {
+            if (c->mh_defer && !c->tiled) {
                 // real + virtual positions: the windows of this launch tile the cube
                 const int n_all = c->colour_off[col + 1] - c->colour_off[col];
                 int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
                 if (rc) return rc;
                 c->gpar ^= 1;  // this launch's updates are now the pending ones
-                c->pend_cy = col / c->fw;
-                c->pend_cx = col % c->fw;
+                c->pend_cy = ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
+                c->pend_cx = ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw;
             } else {
                 int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s);
                 if (rc) return rc;
@@ -1031,6 +1048,92 @@ int d3d_get_dlog(d3d_ctx *c, double *out_hw) {
     NEED(c && out_hw, D3D_ERR_INVALID, "NULL argument");
     HIP_TRY(hipMemcpyAsync(out_hw, c->dlog, (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_set_tile(d3d_ctx *c, int gy0, int gx0, int Wg, int oy0, int oy1, int ox0, int ox1) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(gy0 >= 0 && gx0 >= 0 && Wg >= gx0 + c->W, D3D_ERR_INVALID,
+         "tile origin (%d,%d) / global width %d inconsistent with local width %d", gy0, gx0, Wg,
+         c->W);
+    NEED(0 <= oy0 && oy0 <= oy1 && oy1 <= c->H && 0 <= ox0 && ox0 <= ox1 && ox1 <= c->W,
+         D3D_ERR_INVALID, "owned rectangle [%d,%d)x[%d,%d) outside the tile", oy0, oy1, ox0, ox1);
+    c->gy0 = gy0;
+    c->gx0 = gx0;
+    c->Wg = Wg;
+    c->oy0 = oy0;
+    c->oy1 = oy1;
+    c->ox0 = ox0;
+    c->ox1 = ox1;
+    c->tiled = true;
+    c->pend_cy = c->pend_cx = -1;
+    if (c->have_data) return build_colour_lists(c);
+    return D3D_OK;
+}
+
+int d3d_mh_colour(d3d_ctx *c, int colour, int sweep) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,
+         "taps/data/parameters/mh_config not set");
+    NEED(colour >= 0 && colour < c->fh * c->fw && sweep >= 0, D3D_ERR_INVALID,
+         "colour %d / sweep %d out of range", colour, sweep);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->err_valid) {
+        int rc = d3d_residual(c, nullptr);
+        if (rc) return rc;
+    }
+    if (int rc = flush_pending(c)) return rc;
+    const int n_real = c->colour_real[colour];
+    if (n_real <= 0) return D3D_OK;
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    P.spx = c->spx + c->colour_off[colour];
+    return launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep);
+}
+
+int d3d_export_updates(d3d_ctx *c, int n, const int *spaxels, double *out) {
+    NEED(c && (n == 0 || (spaxels && out)), D3D_ERR_INVALID, "NULL argument");
+    NEED(n >= 0 && n <= c->HW, D3D_ERR_INVALID, "bad record count %d", n);
+    if (n == 0) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->idxbuf, spaxels, (size_t)n * sizeof(int), hipMemcpyHostToDevice,
+                           c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    hipLaunchKernelGGL(d3d::k_gather_updates, dim3((n + 255) / 256), dim3(256), 0, c->stream, P,
+                       (const int *)c->idxbuf, n, c->recbuf);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->recbuf, (size_t)n * 8 * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_apply_updates(d3d_ctx *c, int n, const double *records) {
+    NEED(c && (n == 0 || records), D3D_ERR_INVALID, "NULL argument");
+    NEED(n >= 0 && n <= c->HW, D3D_ERR_INVALID, "bad record count %d", n);
+    NEED(c->have_taps && c->have_data, D3D_ERR_STATE, "taps/data not set");
+    if (n == 0) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->err_valid) {
+        int rc = d3d_residual(c, nullptr);
+        if (rc) return rc;
+    }
+    if (int rc = flush_pending(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->recbuf, records, (size_t)n * 8 * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const size_t lds = (size_t)(2 * c->N + c->Dp) * sizeof(double);
+    if (c->HL <= 256) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<256>), dim3((unsigned)n), dim3(256),
+                           lds, c->stream, P, (const double *)c->recbuf, n);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<1024>), dim3((unsigned)n),
+                           dim3(1024), lds, c->stream, P, (const double *)c->recbuf, n);
+    }
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D3D_OK;
 }

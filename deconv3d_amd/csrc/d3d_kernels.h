@@ -561,6 +561,7 @@ struct MHArgs {
     double *err;
     const double *ivar;
     double *params;
+    double *prev;  // [H*W*3] parameters before the last update of each spaxel, or NULL
     const double *fsf;
     const int *shift;
     const double *weight;
@@ -617,6 +618,13 @@ __device__ __forceinline__ MHShared mh_carve(double *smem, int NT, int HL, int D
     S.G = S.gN + N;
     S.sum = S.G + Dp;
     return S;
+}
+
+// Residual update coefficient of one channel: err += f * G, G = a_old*E_old -
+// r*E_end (lib/run.py:508-515).  One definition (explicit fma) so that the
+// owner's kernel and a neighbour tile's replay (k_apply_updates) round alike.
+__device__ __forceinline__ double residual_coeff(double a_old, double EO, double r, double Eend) {
+    return fma(-r, Eend, a_old * EO);
 }
 
 // ---- the decision, in three steps shared by every MH kernel ---------------
@@ -764,8 +772,13 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
         truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep, &blk);
 
     // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
-    *Gz_out = (ch < D) ? (Lo - r * Eend) : 0.0;
+    *Gz_out = (ch < D) ? residual_coeff(q.a_old, EO, r, Eend) : 0.0;
     if (ch == 0) {
+        if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
+            P.prev[(long)sp * 3 + 0] = q.a_old;
+            P.prev[(long)sp * 3 + 1] = q.c_old;
+            P.prev[(long)sp * 3 + 2] = q.w_old;
+        }
         P.params[(long)sp * 3 + 0] = r;
         P.params[(long)sp * 3 + 1] = c_end;
         P.params[(long)sp * 3 + 2] = w_end;
@@ -1149,6 +1162,77 @@ __global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t swee
     double Gt;
     if (!mh_finish(P, S, q, sp, sweep, ch, G, EO, EN, NS / 64, NPW, !streamer, &Gt)) return;
     if (ch < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + ch] = Gt;
+}
+
+// Replay of updates made by ANOTHER tile (multi-GPU spatial tiling): one
+// workgroup per record {ly, lx, a_old, c_old, w_old, a_new, c_new, w_new} with
+// (ly, lx) in this tile's local coordinates (possibly outside it).  Recomputes
+// the update coefficient exactly as the owner did and applies err += f*G on the
+// part of the window that lies inside the local region; spaxels inside the
+// region also get their parameters.  Thread t <-> channel t for the lines, then
+// z-pairs for the window.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_apply_updates(MHArgs P, const double *__restrict__ rec,
+                                                      int nrec) {
+    extern __shared__ double smem[];
+    double *gO = smem;          // [N]
+    double *gN = gO + P.N;      // [N]
+    double *sG = gN + P.N;      // [Dp]
+    const int tid = threadIdx.x;
+    const double *r8 = rec + (long)blockIdx.x * 8;
+    const int y = (int)r8[0], x = (int)r8[1];
+    const double a_old = r8[2], c_old = r8[3], w_old = r8[4];
+    const double a_new = r8[5], c_new = r8[6], w_new = r8[7];
+    for (int j = tid; j < P.N; j += NT) {
+        gO[j] = (j < P.D) ? unit_gaussian((double)j, c_old, w_old) : 0.0;
+        gN[j] = (j < P.D) ? unit_gaussian((double)j, c_new, w_new) : 0.0;
+    }
+    __syncthreads();
+    for (int ch = tid; ch < P.Dp; ch += NT) {
+        double EO, EN;
+        mh_lsf(P, gO, gN, ch, &EO, &EN);
+        sG[ch] = (ch < P.D) ? residual_coeff(a_old, EO, a_new, EN) : 0.0;
+    }
+    if (tid == 0 && y >= 0 && y < P.H && x >= 0 && x < P.W) {
+        const long sp = (long)y * P.W + x;
+        P.params[sp * 3 + 0] = a_new;
+        P.params[sp * 3 + 1] = c_new;
+        P.params[sp * 3 + 2] = w_new;
+    }
+    __syncthreads();
+    const int HL = P.HL, G = NT / HL;
+    const int g = tid / HL, zl = tid - g * HL;
+    if (g >= G) return;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const double2 Gz = *reinterpret_cast<const double2 *>(sG + 2 * zl);
+    for (int p = g; p < P.npos; p += G) {
+        const int dy = p / P.fw, dx = p - dy * P.fw;
+        const int yy = y + dy - fhh, xx = x + dx - fhw;
+        if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+        const long idx = ((long)yy * P.W + xx) * P.Dp + 2 * zl;
+        const double f = P.fsf[p];
+        double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
+        e.x = fma(f, Gz.x, e.x);
+        e.y = fma(f, Gz.y, e.y);
+        *reinterpret_cast<double2 *>(P.err + idx) = e;
+    }
+}
+
+// Records of the last update of the listed spaxels, for a neighbour tile:
+// {global y, global x, a_old, c_old, w_old, a_new, c_new, w_new}.
+__global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
+                                 double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sp = idx[i];
+    const int y = sp / P.W, x = sp - y * P.W;
+    double *o = out + (long)i * 8;
+    o[0] = (double)(y + P.gy0);
+    o[1] = (double)(x + P.gx0);
+    for (int k = 0; k < 3; ++k) {
+        o[2 + k] = P.prev[(long)sp * 3 + k];
+        o[5 + k] = P.params[(long)sp * 3 + k];
+    }
 }
 
 // Apply the pending updates of colour (prev_cy, prev_cx) to the whole residual

@@ -147,10 +147,31 @@ int d3d_mh_sweeps(d3d_ctx *ctx, int n_sweeps, int first_sweep, int keep_one_in,
 /* Last sweep's log acceptance ratios, (H,W). */
 int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
 
-/* ---- spatial tiling (multi-GPU halo exchange) ----------- */
+/* ---- spatial tiling (one chain over several GPUs) --------- */
+/* The reference has no counterpart (single process).  A tile ctx holds a
+ * sub-region of the global cube: its owned spaxels plus a frame of FSF
+ * half-width cells.  Random numbers and colour classes are keyed by GLOBAL
+ * coordinates, so the tiled chain is bit-identical to the single-device one;
+ * updates of spaxels near a tile border are exchanged as 8-double records and
+ * replayed by the neighbours (deconv3d_amd/tiling.py drives the exchange over
+ * torch.distributed / RCCL). */
 
-/* Number of unmasked spaxels of colour (cy,cx) = (y mod fh, x mod fw). */
+/* Declare this ctx a tile: its (H,W) cube is the region starting at global
+ * (gy0,gx0) of a cube Wg spaxels wide; it owns local rows [oy0,oy1) and columns
+ * [ox0,ox1) (other spaxels are never updated here).  Call before d3d_set_data. */
+int d3d_set_tile(d3d_ctx *ctx, int gy0, int gx0, int Wg, int oy0, int oy1, int ox0, int ox1);
+/* Number of owned unmasked spaxels of global colour (cy,cx) = ((y+gy0) mod fh,
+ * (x+gx0) mod fw), colour = cy*fw + cx. */
 int d3d_colour_count(d3d_ctx *ctx, int colour, int *count);
+/* One colour class of sweep `sweep` (lib/run.py:367-519 restricted to the
+ * class), residual written back immediately. */
+int d3d_mh_colour(d3d_ctx *ctx, int colour, int sweep);
+/* Records {global y, global x, a,c,w before, a,c,w after} of the last update of
+ * the n listed local spaxels (y*W+x), out[n*8]. */
+int d3d_export_updates(d3d_ctx *ctx, int n, const int *spaxels, double *out);
+/* Replay n records whose first two entries are LOCAL coordinates of this tile
+ * (they may lie outside it): err += f*G on the window's part inside the tile. */
+int d3d_apply_updates(d3d_ctx *ctx, int n, const double *records);
 
 #ifdef __cplusplus
 }

@@ -513,7 +513,8 @@ class MHState(object):
     """Mutable chain state of the oracle sampler."""
 
     def __init__(self, data, var, mask, fsf, lsf, params, min_b, max_b,
-                 jump_amplitude=0.1, gibbs_apriori_variance=None, seed=12345):
+                 jump_amplitude=0.1, gibbs_apriori_variance=None, seed=12345,
+                 origin=None, err=None):
         self.data = np.asarray(data, dtype=np.float64)
         self.var = np.asarray(var, dtype=np.float64)
         self.mask = np.asarray(mask)
@@ -522,6 +523,10 @@ class MHState(object):
         self.params = np.array(params, dtype=np.float64)
         self.min_b = np.asarray(min_b, dtype=np.float64)
         self.max_b = np.asarray(max_b, dtype=np.float64)
+        # (gy0, gx0, Wg): this state is a tile of a wider cube; Philox keys use
+        # the GLOBAL spaxel index (multi-GPU tiling).  None: the whole cube.
+        self.origin = origin if origin is not None else (0, 0, self.data.shape[2])
+        self.last = None  # (p_old, p_end) of the last update
         amp = np.ones(3) * np.array(jump_amplitude)   # lib/run.py:251-252
         amp[0] = 0.                                   # lib/run.py:262
         self.amp = amp
@@ -529,8 +534,8 @@ class MHState(object):
             gibbs_apriori_variance = float(self.max_b[0] ** 2)
         self.ra = gibbs_apriori_variance
         self.seed = seed
-        self.err = compute_error_in_one_step(
-            self.data, self.params, self.mask, self.fsf, self.lsf)
+        self.err = np.array(err, dtype=np.float64) if err is not None else \
+            compute_error_in_one_step(self.data, self.params, self.mask, self.fsf, self.lsf)
         self.accepted = 0
         self.dlog = np.zeros(self.mask.shape)
 
@@ -560,7 +565,8 @@ def mh_update(st, y, x, sweep):
     """
     D, H, W = st.data.shape
     fh, fw = st.fsf.shape
-    sp = y * W + x
+    gy0, gx0, Wg = st.origin
+    sp = (y + gy0) * Wg + (x + gx0)      # global spaxel index keys the RNG
     p_old = st.params[y, x].copy()
 
     # lib/run.py:570-579 Cauchy jump
@@ -606,7 +612,32 @@ def mh_update(st, y, x, sweep):
     p_end[0] = r
     st.err[:, y0:y1, x0:x1] = ul - ek * r    # lib/run.py:508-515
     st.params[y, x] = p_end
+    st.last = (p_old, p_end.copy())
     return accepted
+
+
+def replay_update(st, y, x, p_old, p_end):
+    """
+    Residual change of an update made by ANOTHER tile at local (y, x) (possibly
+    outside this tile): the same (e + c_old) - ek*r of mh_update on the part of
+    the window inside this tile.  Not in the reference (single process).
+    """
+    D, H, W = st.data.shape
+    fh, fw = st.fsf.shape
+    fhh, fhw = (fh - 1) // 2, (fw - 1) // 2
+    y0, y1 = max(y - fhh, 0), min(y + fhh + 1, H)
+    x0, x1 = max(x - fhw, 0), min(x + fhw + 1, W)
+    if y0 >= y1 or x0 >= x1:
+        return
+    ly0, ly1 = y0 - (y - fhh), y1 - (y - fhh)
+    lx0, lx1 = x0 - (x - fhw), x1 - (x - fhw)
+    c_old = local_contribution(p_old, D, st.fsf, st.lsf)[:, ly0:ly1, lx0:lx1]
+    p_one = np.array(p_end, dtype=np.float64).copy()
+    p_one[0] = 1.
+    ek = local_contribution(p_one, D, st.fsf, st.lsf)[:, ly0:ly1, lx0:lx1]
+    st.err[:, y0:y1, x0:x1] = (st.err[:, y0:y1, x0:x1] + c_old) - ek * p_end[0]
+    if 0 <= y < H and 0 <= x < W:
+        st.params[y, x] = p_end
 
 
 def mh_sweep(st, sweep, order=None):
