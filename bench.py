@@ -97,6 +97,8 @@ def cpu_baseline(data, var, mask, fsf, lsf, params, min_b, max_b, err, budget_s)
     st.amp = np.array([0., 0.1, 0.1])
     st.ra = float(max_b[0] ** 2)
     st.seed = 12345
+    st.origin = (0, 0, data.shape[2])
+    st.last = None
     st.err = np.array(err)
     st.accepted = 0
     st.dlog = np.zeros(mask.shape)
@@ -109,6 +111,30 @@ def cpu_baseline(data, var, mask, fsf, lsf, params, min_b, max_b, err, budget_s)
             break
     dt = time.perf_counter() - t0
     return n / dt, n, dt
+
+
+def measured_traffic(kernel_prefix, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes
+    (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
+    [gfx950 correction] + WRITE_SIZE KiB, separate passes); None if the profile
+    on record is for another workload."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if not os.path.isdir(pdir):
+        return None
+    for name in sorted(os.listdir(pdir)):
+        if not name.endswith("_traffic.json"):
+            continue
+        try:
+            rec = json.load(open(os.path.join(pdir, name)))
+        except ValueError:
+            continue
+        if rec.get("workload") != workload:
+            continue
+        for k, v in rec.get("hbm_bytes_per_launch", {}).items():
+            if k.split("::")[-1].startswith(kernel_prefix):
+                best = int(v)
+    return best
 
 
 def main():
@@ -205,9 +231,10 @@ def main():
     launches = ncol * args.steps
     avg_launch_us = dev_ms * 1e3 / launches
     achieved = bytes_per_sweep / ncol / (avg_launch_us * 1e-6) / 1e9
-    roofline = {"kernel": "k_mh", "bound": "hbm", "achieved": round(achieved, 1),
+    roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
+                "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic("k_mh", args.workload),
                 "bytes_per_launch": bytes_per_sweep // ncol,
                 "avg_launch_us": round(avg_launch_us, 2), "launches": launches}
 
@@ -224,7 +251,8 @@ def main():
     conv_gbs = conv_bytes / (conv_ms * 1e-3) / 1e9
     roofline_conv = {"kernel": "k_spectral+k_spatial", "bound": "hbm",
                      "achieved": round(conv_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(conv_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(conv_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": measured_traffic("k_spatial", args.workload),
                      "ms_per_conv": round(conv_ms, 4),
                      "fp64_tflops": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                      "fp64_frac": round(conv_flops / (conv_ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)}

@@ -210,6 +210,7 @@ struct SpatialArgs {
     // wl[j], j = 0..2*LSF_RL, so that out[k] = sum_j wl[j] * v[(k + j - LSF_RL) mod Dp]
     // (closed form of convolve_1d for power-of-two depths, lib/convolution.py:89-120)
     const double *lsf_dense;
+    int xcd_remap;  // XCD-aware block order in the march kernel
 };
 
 // Register-tiled: a thread owns one z-pair and TX consecutive x outputs of one
@@ -306,7 +307,16 @@ __global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
     if constexpr (UNI) s = __builtin_amdgcn_readfirstlane(s);
     const int nxs = (A.W + TX - 1) / TX;
     const int nys = (A.H + HY - 1) / HY;
-    const long item = (long)blockIdx.x * S + s;
+    // XCD-aware block order: workgroups b and b+8 share an XCD (and its L2), so
+    // consecutive LOGICAL blocks -- x-neighbours of one row strip, which read
+    // the same input rows at the same time with FS-1 common columns -- are laid
+    // on one XCD (bijective remap, cdna guide T1).
+    int blk = blockIdx.x;
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+    }
+    const long item = (long)blk * S + s;
     if (s >= S || item >= (long)nxs * nys) return;
     const int ys = (int)(item / nxs);
     const int x0 = (int)(item - (long)ys * nxs) * TX;
