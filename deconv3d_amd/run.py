@@ -55,7 +55,9 @@ class Run:
     (FITS path or Cube), ``instrument``, ``mask``, ``variance``, ``model``,
     ``initial_parameters``, ``jump_amplitude``, ``gibbs_apriori_variance``,
     ``max_iterations``, ``keep_one_in``, ``write_every``,
-    ``min_acceptance_rate``; plus ``seed``, ``device``, ``refresh_every``.
+    ``min_acceptance_rate``; plus ``seed``, ``device``, ``refresh_every``,
+    ``sweeps_per_call`` and ``checkpoint`` (file prefix written every
+    ``write_every`` iterations).
     """
 
     def __init__(
@@ -76,6 +78,7 @@ class Run:
         device=0,
         refresh_every=1000,
         sweeps_per_call=None,
+        checkpoint=None,
     ):
         # lib/run.py:112-114
         assert keep_one_in > 0, "keep_one_in= MUST be a positive integer"
@@ -240,7 +243,13 @@ class Run:
                              (cur_iteration + 1, max_iterations, 100 * cur_acceptance_rate))
             accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
                                                     self.chain, likelihoods)
+            before = cur_iteration
             cur_iteration += n
+            # write_every: documented (lib/run.py:89-92) but never used by the
+            # reference; here it is the checkpoint cadence when a path is given
+            if checkpoint is not None and before // write_every != cur_iteration // write_every:
+                self.iterations_done = cur_iteration
+                self._write_checkpoint(checkpoint, cur_iteration, accepted_count)
         self.iterations_done = cur_iteration
         self.acceptance_rate = float(accepted_count) / float(max(spaxels_count * cur_iteration, 1))
 
@@ -269,6 +278,15 @@ class Run:
                 "deconv3d_amd evaluates the line model on the GPU and implements "
                 "SingleGaussianLineModel (optionally with overridden boundaries); custom "
                 "modelize()/post_jump()/gibbs index are not supported yet.")
+
+    def _write_checkpoint(self, name, iteration, accepted_count):
+        """`<name>_parameters.npy` (current map, reusable as initial_parameters,
+        lib/run.py:790-797) and `<name>_chain.npy` (slots written so far)."""
+        np.save("%s_parameters.npy" % name, self.engine.get_params())
+        n_valid = (iteration - 1) // self.keep_one_in + 1
+        np.save("%s_chain.npy" % name, self.chain[:n_valid])
+        self.logger.info("checkpoint at iteration %d (%d accepted) -> %s_*.npy"
+                         % (iteration, accepted_count, name))
 
     # ITERATORS ###############################################################
 

@@ -199,3 +199,19 @@ def test_min_acceptance_rate_stops_the_loop():
     run = d3d.Run(cube, inst, variance=var, max_iterations=50, min_acceptance_rate=0.999,
                   jump_amplitude=5.0)
     assert run.iterations_done < 50
+
+
+def test_write_every_checkpoints_and_resume(tmp_path):
+    """`write_every` (accepted but unused by the reference, lib/run.py:89-92,107)
+    is the checkpoint cadence: the parameter map on disk restarts a run."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=4)
+    name = str(tmp_path / "ck")
+    run = d3d.Run(cube, inst, variance=var, max_iterations=13, write_every=4, keep_one_in=2,
+                  checkpoint=name, seed=3)
+    ck = np.load(name + "_parameters.npy")
+    assert ck.shape == (9, 9, 3)
+    chain = np.load(name + "_chain.npy")
+    np.testing.assert_array_equal(chain, run.chain[:chain.shape[0]])
+    again = d3d.Run(cube, inst, variance=var, initial_parameters=name + "_parameters.npy",
+                    max_iterations=1)
+    np.testing.assert_array_equal(again.chain[0], ck)
