@@ -104,11 +104,14 @@ struct d3d_ctx {
     double *recbuf = nullptr;        // [HW*8] staging of update records
     int *idxbuf = nullptr;           // [HW] staging of spaxel lists
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
+    bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
-    int march_mode = 2;           // 0: tile kernel, 1: march, 2: march + x symmetry when the FSF has it
+    // 0: tile kernel; 1: march; 2: march + the mirror symmetries the FSF has (x, and y on
+    // top of x); 3: march + x symmetry only
+    int march_mode = 2;
     int sp_nt = 256;              // spectral / spatial block size
 };
 
@@ -219,7 +222,7 @@ int launch_spatial_fw(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, d
     return 0;
 }
 
-template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE>
+template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE, bool SYMY>
 int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     const int S = NT / c->HL;
     const int HY = c->march_hy;
@@ -227,7 +230,7 @@ int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double
     const unsigned grid = (unsigned)((items + S - 1) / S);
     const size_t lds =
         FUSE ? (size_t)S * TX * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double) : 0;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI, FUSE>),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI, FUSE, SYMY>),
                        dim3(grid), dim3(NT), lds, c->stream, A, in, out, HY);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -237,13 +240,16 @@ template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
-    const bool sym = c->march_mode == 2 && c->fsf_symx;
+    const bool symx = c->march_mode >= 2 && c->fsf_symx;
+    const bool symxy = symx && c->fsf_symy && c->march_mode != 3;  // mode 3: x symmetry only
     if (uni) {
-        if (sym) return launch_march<NT, FS, TX, true, true, FUSE>(c, A, in, out);
-        return launch_march<NT, FS, TX, false, true, FUSE>(c, A, in, out);
+        if (symxy) return launch_march<NT, FS, TX, true, true, FUSE, true>(c, A, in, out);
+        if (symx) return launch_march<NT, FS, TX, true, true, FUSE, false>(c, A, in, out);
+        return launch_march<NT, FS, TX, false, true, FUSE, false>(c, A, in, out);
     }
-    if (sym) return launch_march<NT, FS, TX, true, false, FUSE>(c, A, in, out);
-    return launch_march<NT, FS, TX, false, false, FUSE>(c, A, in, out);
+    if (symxy) return launch_march<NT, FS, TX, true, false, FUSE, true>(c, A, in, out);
+    if (symx) return launch_march<NT, FS, TX, true, false, FUSE, false>(c, A, in, out);
+    return launch_march<NT, FS, TX, false, false, FUSE, false>(c, A, in, out);
 }
 
 template <int NT, bool FUSE>
@@ -323,7 +329,12 @@ bool can_fuse_lsf(const d3d_ctx *c) {
 // fuse_lsf: also apply the LSF along z (only when can_fuse_lsf()).
 int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
                    bool fuse_lsf = false) {
-    switch (pick_nt(c->HL)) {
+    int nt = pick_nt(c->HL);
+    if (const char *e = getenv("D3D_SPATIAL_NT")) {
+        const int v = atoi(e);
+        if ((v == 256 || v == 512 || v == 1024) && v >= nt) nt = v;
+    }
+    switch (nt) {
         case 256: return launch_spatial_nt<256>(c, in, out, data, fuse_lsf);
         case 512: return launch_spatial_nt<512>(c, in, out, data, fuse_lsf);
         default: return launch_spatial_nt<1024>(c, in, out, data, fuse_lsf);
@@ -710,6 +721,13 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
         for (int i = 0; i < c->fw / 2; ++i)
             if (fsf[k * c->fw + i] != fsf[k * c->fw + (c->fw - 1 - i)]) {
                 c->fsf_symx = false;
+                break;
+            }
+    c->fsf_symy = true;
+    for (int k = 0; k < c->fh / 2 && c->fsf_symy; ++k)
+        for (int i = 0; i < c->fw; ++i)
+            if (fsf[k * c->fw + i] != fsf[(c->fh - 1 - k) * c->fw + i]) {
+                c->fsf_symy = false;
                 break;
             }
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);

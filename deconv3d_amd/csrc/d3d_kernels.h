@@ -288,8 +288,8 @@ __global__ __launch_bounds__(NT) void k_spatial(SpatialArgs A, const double *__r
 //         for every Gaussian/Moffat with pa = 0): the mirrored inputs are
 //         summed once per input row and shared by all FS slots, (FS+1)/2 FMAs
 //         per tap row instead of FS.
-template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE>
-__global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
+template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE, bool SYMY>
+__global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
     SpatialArgs A, const double *__restrict__ in, double *__restrict__ out, int HY) {
     constexpr int FHH = (FS - 1) / 2;
     constexpr int NP = SYMX ? (FHH + 1) : FS;  // products per (slot, column)
@@ -370,30 +370,79 @@ __global__ __launch_bounds__(NT, (2 * NT) / 256) void k_spatial_march(
                     P[t][FHH] = row[t + FHH];
                 }
             }
+            if constexpr (SYMX && SYMY) {
+                // FSF also mirror-symmetric in y (fsf[k][i] == fsf[FS-1-k][i]): tap
+                // rows FHH-a and FHH+a are the same, so their dot product with the
+                // folded inputs, T_a = sum_m fsf[FHH-a][m] * P[.][m], is formed once
+                // and ADDED to the two ring slots FHH-a (output row r-a) and FHH+a
+                // (output row r+a): (FHH+1)^2 FMAs + FS adds per column instead of
+                // FS*(FHH+1) FMAs.
 #pragma unroll
-            for (int k = 0; k < FS; ++k) {
+                for (int m = 0; m < NP; ++m) tcur[m] = taps[FHH * FS + m];
 #pragma unroll
-                for (int m = 0; m < NP; ++m) tnxt[m] = taps[(k + 1) * FS + m];
-                const int oy = r - FHH + k;
-                if (oy >= y0 && oy < yend) {
+                for (int a = 0; a <= FHH; ++a) {
 #pragma unroll
-                    for (int m = 0; m < NP; ++m) {
-                        const double tap = tcur[m];
+                    for (int m = 0; m < NP; ++m)
+                        tnxt[m] = taps[(a < FHH ? FHH - a - 1 : FS) * FS + m];
+                    const bool lo_ok = (r - a >= y0) && (r - a < yend);
+                    const bool hi_ok = (a > 0) && (r + a >= y0) && (r + a < yend);
+                    if (lo_ok || hi_ok) {
+                        double2 T[TX];
 #pragma unroll
-                        for (int t = 0; t < TX; ++t) {
-                            double2 x;
-                            if constexpr (SYMX) {
-                                x = P[t][m];
-                            } else {
-                                x = row[t + FS - 1 - m];
+                        for (int t = 0; t < TX; ++t) T[t] = make_double2(0.0, 0.0);
+#pragma unroll
+                        for (int m = 0; m < NP; ++m) {
+                            const double tap = tcur[m];
+#pragma unroll
+                            for (int t = 0; t < TX; ++t) {
+                                T[t].x = fma(tap, P[t][m].x, T[t].x);
+                                T[t].y = fma(tap, P[t][m].y, T[t].y);
                             }
-                            ring[k][t].x = fma(tap, x.x, ring[k][t].x);
-                            ring[k][t].y = fma(tap, x.y, ring[k][t].y);
+                        }
+                        if (lo_ok) {
+#pragma unroll
+                            for (int t = 0; t < TX; ++t) {
+                                ring[FHH - a][t].x += T[t].x;
+                                ring[FHH - a][t].y += T[t].y;
+                            }
+                        }
+                        if (hi_ok) {
+#pragma unroll
+                            for (int t = 0; t < TX; ++t) {
+                                ring[FHH + a][t].x += T[t].x;
+                                ring[FHH + a][t].y += T[t].y;
+                            }
                         }
                     }
-                }
 #pragma unroll
-                for (int m = 0; m < NP; ++m) tcur[m] = tnxt[m];
+                    for (int m = 0; m < NP; ++m) tcur[m] = tnxt[m];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < FS; ++k) {
+#pragma unroll
+                    for (int m = 0; m < NP; ++m) tnxt[m] = taps[(k + 1) * FS + m];
+                    const int oy = r - FHH + k;
+                    if (oy >= y0 && oy < yend) {
+#pragma unroll
+                        for (int m = 0; m < NP; ++m) {
+                            const double tap = tcur[m];
+#pragma unroll
+                            for (int t = 0; t < TX; ++t) {
+                                double2 x;
+                                if constexpr (SYMX) {
+                                    x = P[t][m];
+                                } else {
+                                    x = row[t + FS - 1 - m];
+                                }
+                                ring[k][t].x = fma(tap, x.x, ring[k][t].x);
+                                ring[k][t].y = fma(tap, x.y, ring[k][t].y);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int m = 0; m < NP; ++m) tcur[m] = tnxt[m];
+                }
             }
         }
         const int oy0 = r - FHH;  // slot 0 has received its last tap row
