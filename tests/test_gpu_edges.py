@@ -1,0 +1,178 @@
+"""
+GPU edge cases of the hot path (through the C ABI): NaN voxels and zero
+variance (lib/run.py:153-165, 174-182), deep cubes (every MH kernel geometry),
+the depth limit, degenerate widths, masks that empty a colour class.
+"""
+import numpy as np
+import pytest
+
+from deconv3d_amd import _lib
+from oracle import deconv3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def small_problem(D, H, W, fsf, lsf, seed=0):
+    rng = np.random.default_rng(seed)
+    truth = np.dstack((1 + 5 * rng.random((H, W)), D * (0.3 + 0.4 * rng.random((H, W))),
+                       1.0 + 2 * rng.random((H, W))))
+    mask = np.ones((H, W))
+    clean = O.forward_full((D, H, W), truth, mask, fsf, lsf)
+    sigma = 0.05 * clean.max()
+    data = clean + rng.normal(0, sigma, clean.shape)
+    var = np.full(clean.shape, sigma ** 2)
+    min_b = O.model_min_boundaries()
+    max_b = O.model_max_boundaries(data, fsf)
+    init = min_b + (max_b - min_b) * rng.random((H, W, 3))
+    init[..., 2] = np.maximum(init[..., 2], 0.5)
+    return data, var, mask, truth, init, min_b, max_b
+
+
+@pytest.mark.parametrize("D", [100, 128, 200, 256, 300, 512, 1000, 1024])
+def test_deep_cubes_chain_matches_oracle(D):
+    """Depths that select every MH kernel: wave-specialised (D <= 256, 2 or 4
+    prepare waves), plain deferred (D > 256), 256/512/1024-thread blocks, and
+    non-power-of-two depths with the partial-wrap LSF."""
+    H, W = 5, 6
+    fsf = O.gaussian_fsf_image(1.6)
+    lsf = O.gaussian_lsf_vector(D, 1.1)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=D)
+    st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, seed=3)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(truth)
+        sim = eng.forward()
+        ref = O.forward_full((D, H, W), truth, mask, fsf, lsf)
+        assert np.max(np.abs(sim - ref)) <= 1e-12 * np.max(np.abs(ref))
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, st.ra, seed=3, refresh_every=0)
+        eng.mh_sweeps(2, 1)
+        for s in (1, 2):
+            O.mh_sweep(st, s)
+        np.testing.assert_allclose(eng.get_params(), st.params, rtol=1e-9, atol=1e-9)
+        err = eng.download_slot(_lib.SLOT_ERR)
+        assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
+
+
+def test_depth_limit_is_reported():
+    with pytest.raises(NotImplementedError, match="1024"):
+        _lib.Engine((1025, 4, 4), (3, 3))
+
+
+def test_nan_voxels_and_zero_variance():
+    """NaN voxels get zero weight (nansum of lib/run.py:423-424), a spaxel with a
+    NaN anywhere in its spectrum is never iterated (lib/run.py:159-162), zero
+    variance becomes 1e12 (lib/run.py:180)."""
+    D, H, W = 32, 10, 11
+    fsf = O.gaussian_fsf_image(2.0)
+    lsf = O.gaussian_lsf_vector(D, 0.8)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=1)
+    data[5, 4, 6] = np.nan
+    data[:, 0, 0] = np.nan
+    var[7, 2, 3] = 0.0
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, 50.0, seed=2, refresh_every=0)
+        err = eng.residual()
+        assert np.isfinite(err).all()
+        model = O.forward_full((D, H, W), init, _nanmask(mask, data), fsf, lsf)
+        assert abs(err[5, 4, 6] + model[5, 4, 6]) <= 1e-12 * np.max(np.abs(model))   # data := 0 there
+        # oracle with the same conventions: masked NaN spaxels, data 0 / huge variance there
+        omask = _nanmask(mask, data)
+        odata = np.where(np.isnan(data), 0.0, data)
+        ovar = np.where(var == 0.0, 1e12, var)
+        ovar = np.where(np.isnan(data), np.inf, ovar)
+        cmap, total = eng.chi2_map()
+        ref_map = O.chi2_map(odata - O.forward_full((D, H, W), init, omask, fsf, lsf), ovar)
+        np.testing.assert_allclose(cmap, ref_map, rtol=1e-10, atol=1e-12 * ref_map.sum())
+        st = O.MHState(odata, ovar, omask, fsf, lsf, init, min_b, max_b, gibbs_apriori_variance=50.0,
+                       seed=2)
+        eng.mh_sweeps(2, 1)
+        for s in (1, 2):
+            O.mh_sweep(st, s)
+        p = eng.get_params()
+        assert np.isfinite(p).all()
+        np.testing.assert_allclose(p, st.params, rtol=1e-9, atol=1e-9)
+        np.testing.assert_array_equal(p[4, 6], init[4, 6])      # NaN spectrum: never iterated
+        np.testing.assert_array_equal(p[0, 0], init[0, 0])
+
+
+def _nanmask(mask, data):
+    m = np.array(mask, dtype=float)
+    m[np.isnan(np.sum(data, 0))] = 0
+    return m
+
+
+def test_mask_that_empties_colour_classes_and_single_live_spaxel():
+    D, H, W = 16, 9, 9
+    fsf = O.gaussian_fsf_image(2.0)          # 7x7 -> 49 colours, 81 spaxels
+    lsf = O.gaussian_lsf_vector(D, 0.7)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=2)
+    mask[:] = 0
+    mask[4, 4] = 1
+    mask[8, 0] = 1
+    st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, seed=6)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, st.ra, seed=6, refresh_every=0)
+        assert sum(eng.colour_count(c) for c in range(49)) == 2
+        eng.mh_sweeps(3, 1)
+        for s in (1, 2, 3):
+            O.mh_sweep(st, s)
+        np.testing.assert_allclose(eng.get_params(), st.params, rtol=1e-9, atol=1e-9)
+        err = eng.download_slot(_lib.SLOT_ERR)
+        assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
+    # everything masked: nothing to do, nothing breaks
+    mask[:] = 0
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, 10.0, seed=6, refresh_every=0)
+        assert eng.mh_sweeps(2, 1) == 0
+        np.testing.assert_array_equal(eng.get_params(), init)
+
+
+def test_zero_width_line_is_a_delta_not_nan():
+    """w = 0 is inside the reference's bounds (lib/line_models.py:77) and gives
+    0/0 there (:109); the device builds a delta line at z == c instead."""
+    D, H, W = 16, 4, 4
+    fsf = np.ones((1, 1))
+    data = np.zeros((D, H, W))
+    params = np.zeros((H, W, 3))
+    params[..., 2] = 1.0
+    params[1, 2] = [3.0, 5.0, 0.0]
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, None)
+        eng.set_data(data + 1.0, None, 1.0)
+        eng.set_params(params)
+        clean = eng.build_clean()
+    assert np.isfinite(clean).all()
+    want = np.zeros(D)
+    want[5] = 3.0
+    np.testing.assert_array_equal(clean[:, 1, 2], want)
+
+
+def test_refresh_cadence_inside_mh_sweeps():
+    """refresh_every (lib/run.py:525): the from-scratch residual replaces the
+    carried one without changing the chain beyond round-off."""
+    D, H, W = 16, 8, 8
+    fsf = O.gaussian_fsf_image(2.0)
+    lsf = O.gaussian_lsf_vector(D, 0.7)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=3)
+    outs = []
+    for every in (0, 2):
+        with _lib.Engine((D, H, W), fsf.shape) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.set_data(data, var, mask=mask)
+            eng.set_params(init)
+            eng.mh_config(min_b, max_b, 0.1, 30.0, seed=8, refresh_every=every)
+            eng.mh_sweeps(5, 1)
+            outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR)))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-8, atol=1e-8)
+    assert np.max(np.abs(outs[0][1] - outs[1][1])) <= 1e-10 * np.max(np.abs(outs[0][1]))
