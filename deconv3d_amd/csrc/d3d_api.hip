@@ -284,6 +284,7 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.data = data;
     A.lsf_dense = nullptr;
     A.xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
+    A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
     if (c->march_mode > 0 && c->fh == c->fw) {
         bool done = false;
         int rc;

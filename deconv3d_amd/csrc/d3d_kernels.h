@@ -211,6 +211,7 @@ struct SpatialArgs {
     // (closed form of convolve_1d for power-of-two depths, lib/convolution.py:89-120)
     const double *lsf_dense;
     int xcd_remap;  // XCD-aware block order in the march kernel
+    int alt_dir;    // alternate the march direction of vertically adjacent strips
 };
 
 // Register-tiled: a thread owns one z-pair and TX consecutive x outputs of one
@@ -331,7 +332,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
 #pragma unroll
         for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
 
-    for (int r = y0 - FHH; r < yend + FHH; ++r) {
+    // March direction: with a y-symmetric FSF the stencil is invariant under
+    // y -> -y, so odd row strips walk UP.  Vertically adjacent strips then read
+    // their FS-1 shared halo rows at the same time (both at their start or both
+    // at their end) and, being on the same XCD (remap above), share them in L2:
+    // measured fetch traffic 265 MB -> 131 MB per launch (L2 hit 32 % -> 56 %).
+    const int dir = (SYMY && A.alt_dir && (ys & 1)) ? -1 : 1;
+    const int nsteps = (yend - y0) + 2 * FHH;
+    int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
+    for (int step = 0; step < nsteps; ++step, r += dir) {
         if (r >= 0 && r < A.H) {
             const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
             double2 row[NR];
@@ -384,8 +393,9 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
 #pragma unroll
                     for (int m = 0; m < NP; ++m)
                         tnxt[m] = taps[(a < FHH ? FHH - a - 1 : FS) * FS + m];
-                    const bool lo_ok = (r - a >= y0) && (r - a < yend);
-                    const bool hi_ok = (a > 0) && (r + a >= y0) && (r + a < yend);
+                    const int ylo = r - dir * a, yhi = r + dir * a;  // rows of slots FHH-a, FHH+a
+                    const bool lo_ok = (ylo >= y0) && (ylo < yend);
+                    const bool hi_ok = (a > 0) && (yhi >= y0) && (yhi < yend);
                     if (lo_ok || hi_ok) {
                         double2 T[TX];
 #pragma unroll
@@ -445,7 +455,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                 }
             }
         }
-        const int oy0 = r - FHH;  // slot 0 has received its last tap row
+        const int oy0 = r - dir * FHH;  // slot 0 has received its last tap row
         if (oy0 >= y0 && oy0 < yend) {
             if constexpr (FUSE) {
                 // Spectral (LSF) pass on the finished row before it is stored:
