@@ -109,6 +109,7 @@ struct d3d_ctx {
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
+    int march_pf = 0;             // D3D_MARCH_PF=2|3: software-pipelined variant, TX columns
     // 0: tile kernel; 1: march; 2: march + the mirror symmetries the FSF has (x, and y on
     // top of x); 3: march + x symmetry only
     int march_mode = 2;
@@ -236,13 +237,74 @@ int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double
     return 0;
 }
 
+// Diagnostic build (D3D_STAMP=1): the xy-symmetric march kernel with in-kernel
+// s_memtime stamps; prints the per-phase cycle shares of a march step to stderr.
+template <int NT, int FS, int TX>
+int launch_march_stamped(d3d_ctx *c, d3d::SpatialArgs A, const double *in, double *out) {
+    const int S = NT / c->HL;
+    const int HY = c->march_hy;
+    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
+    const unsigned grid = (unsigned)((items + S - 1) / S);
+    const size_t nw = (size_t)grid * (NT / 64);
+    unsigned long long *dbg = nullptr;
+    HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(dbg, 0, nw * 8 * sizeof(unsigned long long), c->stream));
+    A.dbg = dbg;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, true, true, false, true, true>),
+                       dim3(grid), dim3(NT), 0, c->stream, A, in, out, HY);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> h(nw * 8);
+    HIP_TRY(hipMemcpyAsync(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                           c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(dbg);
+    double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
+    unsigned long long tmin = ~0ULL, tmax = 0;
+    size_t live = 0;
+    for (size_t w = 0; w < nw; ++w) {
+        if (!h[w * 8 + 5]) continue;
+        ++live;
+        for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
+        steps += (double)h[w * 8 + 5];
+        if (h[w * 8 + 6] < tmin) tmin = h[w * 8 + 6];
+        if (h[w * 8 + 7] > tmax) tmax = h[w * 8 + 7];
+    }
+    fprintf(stderr,
+            "[d3d stamp] waves %zu steps/wave %.1f | cycles per step: issue %.0f wait %.0f math %.0f "
+            "tail %.0f | wave lifetime %.0f cyc | kernel span %.0f cyc\n",
+            live, steps / live, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps,
+            sum[4] / live, (double)(tmax - tmin));
+    return 0;
+}
+
 template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool symx = c->march_mode >= 2 && c->fsf_symx;
     const bool symxy = symx && c->fsf_symy && c->march_mode != 3;  // mode 3: x symmetry only
+    if (uni && symxy && !FUSE && c->march_pf > 0) {
+        // software-pipelined variant (next-row loads interleaved with the FMAs)
+        const int HY = c->march_hy;
+        const int S = NT / c->HL;
+        if (c->march_pf == 3) {
+            const long items = (long)((c->W + 2) / 3) * ((c->H + HY - 1) / HY);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march_pf<NT, FS, 3>),
+                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
+                               out, HY);
+        } else {
+            const long items = (long)((c->W + 1) / 2) * ((c->H + HY - 1) / HY);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march_pf<NT, FS, 2>),
+                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
+                               out, HY);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (uni) {
+        if constexpr (FS == 11 && !FUSE && NT == 256) {
+            if (symxy && getenv("D3D_STAMP")) return launch_march_stamped<NT, FS, TX>(c, A, in, out);
+        }
         if (symxy) return launch_march<NT, FS, TX, true, true, FUSE, true>(c, A, in, out);
         if (symx) return launch_march<NT, FS, TX, true, true, FUSE, false>(c, A, in, out);
         return launch_march<NT, FS, TX, false, true, FUSE, false>(c, A, in, out);
@@ -285,6 +347,8 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.lsf_dense = nullptr;
     A.xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
     A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
+    A.dbg = nullptr;
+    A.stagger = getenv("D3D_STAGGER") ? atoi(getenv("D3D_STAGGER")) : 0;
     if (c->march_mode > 0 && c->fh == c->fw) {
         bool done = false;
         int rc;
@@ -732,6 +796,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
                 break;
             }
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
+    if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
     if (const char *e = getenv("D3D_MARCH_HY")) {
         const int v = atoi(e);
         if (v >= 1) c->march_hy = v;

@@ -212,6 +212,10 @@ struct SpatialArgs {
     const double *lsf_dense;
     int xcd_remap;  // XCD-aware block order in the march kernel
     int alt_dir;    // alternate the march direction of vertically adjacent strips
+    int stagger;    // start delay (x ~2000 cycles) of every other workgroup, 0 = none
+    // diagnostic build only (D3D_STAMP=1): per-wavefront cycle sums of the
+    // phases of a march step; a buffer of its own, never read by product code
+    unsigned long long *dbg;
 };
 
 // Register-tiled: a thread owns one z-pair and TX consecutive x outputs of one
@@ -289,7 +293,15 @@ __global__ __launch_bounds__(NT) void k_spatial(SpatialArgs A, const double *__r
 //         for every Gaussian/Moffat with pa = 0): the mirrored inputs are
 //         summed once per input row and shared by all FS slots, (FS+1)/2 FMAs
 //         per tap row instead of FS.
-template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE, bool SYMY>
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+
+template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE, bool SYMY, bool STAMP = false>
 __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
     SpatialArgs A, const double *__restrict__ in, double *__restrict__ out, int HY) {
     constexpr int FHH = (FS - 1) / 2;
@@ -340,7 +352,18 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
     const int dir = (SYMY && A.alt_dir && (ys & 1)) ? -1 : 1;
     const int nsteps = (yend - y0) + 2 * FHH;
     int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
+    // Stagger: co-resident wavefronts run the same program and fall into lock
+    // step (all issue their row loads together, then all compute together).
+    // Delaying every other workgroup by about half a step lets one wave's loads
+    // overlap its SIMD partner's FMAs (cdna guide, 'try a stagger').
+    if (A.stagger > 0 && (((blk >> 3) ^ blk) & 1)) {
+        for (int i = 0; i < A.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    }
+    unsigned long long acc_issue = 0, acc_wait = 0, acc_math = 0, acc_tail = 0, t0 = 0, t1 = 0,
+                       t2 = 0, t3 = 0;
+    const unsigned long long t_begin = STAMP ? stamp() : 0;
     for (int step = 0; step < nsteps; ++step, r += dir) {
+        if constexpr (STAMP) t0 = stamp();
         if (r >= 0 && r < A.H) {
             const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
             double2 row[NR];
@@ -356,6 +379,13 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                                  ? *reinterpret_cast<const double2 *>(base + (long)i * A.Dp)
                                  : make_double2(0.0, 0.0);
                 }
+            }
+            if constexpr (STAMP) {
+                t1 = stamp();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                t2 = stamp();
+                acc_issue += t1 - t0;
+                acc_wait += t2 - t1;
             }
             // Taps are re-read from LDS every step (an opaque zero keeps the
             // compiler from hoisting FS*FS loop-invariant registers out of the
@@ -455,6 +485,10 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                 }
             }
         }
+        if constexpr (STAMP) {
+            t3 = stamp();
+            if (r >= 0 && r < A.H) acc_math += t3 - t2;
+        }
         const int oy0 = r - dir * FHH;  // slot 0 has received its last tap row
         if (oy0 >= y0 && oy0 < yend) {
             if constexpr (FUSE) {
@@ -517,6 +551,169 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
             for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
 #pragma unroll
         for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+        if constexpr (STAMP) acc_tail += stamp() - t3;
+    }
+    if constexpr (STAMP) {
+        const unsigned long long t_end = stamp();
+        if ((threadIdx.x & 63) == 0 && A.dbg) {
+            unsigned long long *d = A.dbg + ((size_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * 8;
+            d[0] = acc_issue;
+            d[1] = acc_wait;
+            d[2] = acc_math;
+            d[3] = acc_tail;
+            d[4] = t_end - t_begin;
+            d[5] = (unsigned long long)nsteps;
+            d[6] = t_begin;
+            d[7] = t_end;
+        }
+    }
+}
+
+// Software-pipelined column march for FSFs that are mirror-symmetric in x AND
+// y, one strip per wavefront (HL multiple of 64).  Same ring / symmetry algebra
+// as k_spatial_march<SYMX, SYMY>; in addition the NEXT input row is loaded while
+// this row is being consumed: its TX+FS-1 loads are issued in small groups
+// between the FHH+1 tap-row blocks, so the memory pipe (64 B/clk per CU, shared
+// by 8 wavefronts) digests them under the FMAs instead of in a burst that stalls
+// every wave of the CU at the same time (in-kernel stamps of the burst form:
+// issue 1300 + wait 680 cycles of a 6500-cycle step).  TX = 2 columns per
+// thread keeps ring + folded row + next row within 256 VGPRs (2 waves/SIMD).
+template <int NT, int FS, int TX>
+__global__ __launch_bounds__(NT, 2) void k_spatial_march_pf(SpatialArgs A,
+                                                            const double *__restrict__ in,
+                                                            double *__restrict__ out, int HY) {
+    constexpr int FHH = (FS - 1) / 2;
+    constexpr int NP = FHH + 1;
+    constexpr int NR = TX + FS - 1;
+    constexpr int CH = (NR + NP - 1) / NP;  // loads issued per tap-row block
+    __shared__ double s_taps[NP * NP + NP];
+    for (int i = threadIdx.x; i < NP * NP + NP; i += NT) {
+        const int k = i / NP, m = i - k * NP;
+        s_taps[i] = k < NP ? A.fsf[k * FS + m] : 0.0;  // rows 0..FHH, columns 0..FHH
+    }
+    __syncthreads();
+
+    const int S = NT / A.HL;
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x / A.HL);
+    const int zl = threadIdx.x - s * A.HL;
+    const int nxs = (A.W + TX - 1) / TX;
+    const int nys = (A.H + HY - 1) / HY;
+    int blk = blockIdx.x;
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+    }
+    const long item = (long)blk * S + s;
+    if (s >= S || item >= (long)nxs * nys) return;
+    const int ys = (int)(item / nxs);
+    const int x0 = (int)(item - (long)ys * nxs) * TX;
+    const int y0 = ys * HY;
+    const int yend = min(y0 + HY, A.H);
+    const long rowstride = (long)A.W * A.Dp;
+    const int dir = (A.alt_dir && (ys & 1)) ? -1 : 1;
+    const int nsteps = (yend - y0) + 2 * FHH;
+    const double *colbase = in + (long)(x0 - FHH) * A.Dp + 2 * zl;
+
+    // column i of input row rr, or zero outside the cube (all tests wave-uniform)
+    auto load_col = [&](int rr, int i) -> double2 {
+        const int xx = x0 - FHH + i;
+        if (rr >= 0 && rr < A.H && xx >= 0 && xx < A.W)
+            return *reinterpret_cast<const double2 *>(colbase + (long)rr * rowstride +
+                                                      (long)i * A.Dp);
+        return make_double2(0.0, 0.0);
+    };
+
+    double2 ring[FS][TX];
+#pragma unroll
+    for (int k = 0; k < FS; ++k)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
+
+    int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
+    double2 cur[NR], nxt[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) cur[i] = load_col(r, i);
+
+    for (int step = 0; step < nsteps; ++step, r += dir) {
+        // fold the row: P[t][m] = cur[t+m] + cur[t+FS-1-m] (m < FHH), centre cur[t+FHH]
+        double2 P[TX][NP];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) {
+#pragma unroll
+            for (int m = 0; m < FHH; ++m) {
+                P[t][m].x = cur[t + m].x + cur[t + FS - 1 - m].x;
+                P[t][m].y = cur[t + m].y + cur[t + FS - 1 - m].y;
+            }
+            P[t][FHH] = cur[t + FHH];
+        }
+        const bool more = step + 1 < nsteps;
+        const int rn = r + dir;
+        int opq = 0;
+        asm volatile("" : "+v"(opq));  // keep the tap reads inside the loop
+        const double *taps = s_taps + opq;
+#pragma unroll
+        for (int a = 0; a <= FHH; ++a) {
+            // a few loads of the next row, then the tap-row block they hide under
+#pragma unroll
+            for (int i = a * CH; i < (a + 1) * CH && i < NR; ++i)
+                nxt[i] = more ? load_col(rn, i) : make_double2(0.0, 0.0);
+            const int ylo = r - dir * a, yhi = r + dir * a;  // rows of slots FHH-a, FHH+a
+            const bool lo_ok = (ylo >= y0) && (ylo < yend);
+            const bool hi_ok = (a > 0) && (yhi >= y0) && (yhi < yend);
+            if (lo_ok || hi_ok) {
+                double2 T[TX];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) T[t] = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int m = 0; m < NP; ++m) {
+                    const double tap = taps[(FHH - a) * NP + m];
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        T[t].x = fma(tap, P[t][m].x, T[t].x);
+                        T[t].y = fma(tap, P[t][m].y, T[t].y);
+                    }
+                }
+                if (lo_ok) {
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        ring[FHH - a][t].x += T[t].x;
+                        ring[FHH - a][t].y += T[t].y;
+                    }
+                }
+                if (hi_ok) {
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        ring[FHH + a][t].x += T[t].x;
+                        ring[FHH + a][t].y += T[t].y;
+                    }
+                }
+            }
+        }
+        const int oy0 = r - dir * FHH;  // slot 0 has received its last tap row
+        if (oy0 >= y0 && oy0 < yend) {
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const int xo = x0 + t;
+                if (xo < A.W) {
+                    const long o = (long)oy0 * rowstride + (long)xo * A.Dp + 2 * zl;
+                    double2 v = ring[0][t];
+                    if (A.data) {
+                        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+                        v.x = d.x - v.x;
+                        v.y = d.y - v.y;
+                    }
+                    *reinterpret_cast<double2 *>(out + o) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FS - 1; ++k)
+#pragma unroll
+            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) cur[i] = nxt[i];
     }
 }
 
