@@ -107,6 +107,7 @@ struct d3d_ctx {
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
+    int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
     int march_pf = 0;             // D3D_MARCH_PF=2|3: software-pipelined variant, TX columns
@@ -204,6 +205,16 @@ int launch_spectral_nt(d3d_ctx *c, const double *in, double *out) {
 }
 
 int launch_spectral(d3d_ctx *c, const double *in, double *out) {
+    if (c->lsf_fusable && c->spectral_dense) {
+        // dense +-LSF_RL taps, spectrum within one wavefront: streaming form
+        const int NT = 256, G = NT / c->HL;
+        const unsigned grid = (unsigned)((c->HW + G - 1) / G);
+        const size_t lds = (size_t)G * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral_dense<256>), dim3(grid), dim3(NT), lds,
+                           c->stream, c->Dp, c->HL, c->HW, (const double *)c->lsf_dense, in, out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     switch (pick_nt(c->HL)) {
         case 256: return launch_spectral_nt<256>(c, in, out);
         case 512: return launch_spectral_nt<512>(c, in, out);
@@ -824,6 +835,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     // dense form for the fused epilogue: out[k] = sum_j wl[j] v[(k + j - RL) mod N]
     c->lsf_fusable = false;
     if (const char *e = getenv("D3D_FUSE_LSF")) c->fuse_lsf = atoi(e);
+    if (const char *e = getenv("D3D_SPECTRAL_DENSE")) c->spectral_dense = atoi(e);
     if (c->ntaps && c->N == c->Dp && c->Dp >= 4 * d3d::LSF_RL && c->HL <= 64 && 64 % c->HL == 0) {
         std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
         bool ok = true;

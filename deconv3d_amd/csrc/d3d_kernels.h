@@ -194,13 +194,54 @@ __global__ __launch_bounds__(NT) void k_spectral(SpectralArgs A, const double *_
     }
 }
 
+constexpr int LSF_RL = 8;  // radius of the LSF taps the dense / fused forms handle
+
+// Fast spectral pass for power-of-two depths whose LSF taps lie within +-LSF_RL
+// channels and whose spectrum fits one wavefront (Dp <= 128):
+//   out[k] = sum_j wl[j] * v[(k + j - LSF_RL) mod Dp]
+// (closed form of convolve_1d, lib/convolution.py:89-120).  The spectrum goes to
+// a wave-private LDS buffer with a circular halo, every lane reads back its
+// aligned window of 2*LSF_RL+2 channels with 16-byte reads (no bank conflicts,
+// no block barrier) and applies the dense taps.  Pure streaming: HBM-bound.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_spectral_dense(int Dp, int HL, long nspax,
+                                                       const double *__restrict__ wl,
+                                                       const double *__restrict__ in,
+                                                       double *__restrict__ out) {
+    extern __shared__ double smem[];
+    constexpr int RL = LSF_RL;
+    const int G = NT / HL;
+    const int g = threadIdx.x / HL, zl = threadIdx.x - g * HL;
+    const long sp = (long)blockIdx.x * G + g;
+    if (g >= G || sp >= nspax) return;
+    double *buf = smem + (size_t)g * (Dp + 2 * RL);
+    const double2 v = *reinterpret_cast<const double2 *>(in + sp * Dp + 2 * zl);
+    *reinterpret_cast<double2 *>(buf + RL + 2 * zl) = v;
+    if (2 * zl < RL) *reinterpret_cast<double2 *>(buf + Dp + RL + 2 * zl) = v;
+    if (2 * zl >= Dp - RL) *reinterpret_cast<double2 *>(buf + RL + 2 * zl - Dp) = v;
+    __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS is in order per wave
+    double w[2 * RL + 2];
+#pragma unroll
+    for (int j = 0; j < RL + 1; ++j) {
+        const double2 p = *reinterpret_cast<const double2 *>(buf + 2 * zl + 2 * j);
+        w[2 * j] = p.x;
+        w[2 * j + 1] = p.y;
+    }
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < 2 * RL + 1; ++j) {
+        const double t = wl[j];
+        acc.x = fma(t, w[j], acc.x);
+        acc.y = fma(t, w[j + 1], acc.y);
+    }
+    *reinterpret_cast<double2 *>(out + sp * Dp + 2 * zl) = acc;
+}
+
 // ------------------------------------------------------------------------- //
 // spatial (FSF) pass: true 2-D convolution, zero boundary, 'same' size        //
 // (scipy.signal.convolve2d(..., mode='same') of lib/run.py:1027-1029)         //
 //   out[Y,X] = sum_{j,i} fsf[j,i] * in[Y - j + fhh, X - i + fhw]              //
 // ------------------------------------------------------------------------- //
-
-constexpr int LSF_RL = 8;  // radius of the LSF taps the fused epilogue handles
 
 struct SpatialArgs {
     int Dp, HL, H, W, fh, fw;
