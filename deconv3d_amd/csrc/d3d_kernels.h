@@ -550,25 +550,30 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                     if (2 * zl >= N - RL) *reinterpret_cast<double2 *>(bt + RL + 2 * zl - N) = v;
                 }
                 __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // re-read the 17 weights here (opaque scalar zero): hoisted out of
+                // the row loop they would pin 34 SGPRs for the whole kernel
+                int opq_s = 0;
+                asm volatile("" : "+s"(opq_s));
+                const double *wl = A.lsf_dense + opq_s;
 #pragma unroll
                 for (int t = 0; t < TX; ++t) {
                     const double *bt = buf + t * (N + 2 * RL) + 2 * zl;
-                    double w[2 * RL + 2];
+                    // streaming form: one 16-byte window read live at a time
+                    //   acc.x = sum_j wl[j] w[j],  acc.y = sum_j wl[j] w[j+1]
+                    double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
                     for (int j = 0; j < RL + 1; ++j) {
                         const double2 p = *reinterpret_cast<const double2 *>(bt + 2 * j);
-                        w[2 * j] = p.x;
-                        w[2 * j + 1] = p.y;
-                    }
-                    double2 acc = make_double2(0.0, 0.0);
-#pragma unroll
-                    for (int j = 0; j < 2 * RL + 1; ++j) {
-                        const double wl = A.lsf_dense[j];
-                        acc.x = fma(wl, w[j], acc.x);
-                        acc.y = fma(wl, w[j + 1], acc.y);
+                        // p = (w[2j], w[2j+1])
+                        if (2 * j <= 2 * RL) acc.x = fma(wl[2 * j], p.x, acc.x);
+                        if (2 * j + 1 <= 2 * RL) acc.x = fma(wl[2 * j + 1], p.y, acc.x);
+                        if (2 * j - 1 >= 0) acc.y = fma(wl[2 * j - 1], p.x, acc.y);
+                        if (2 * j <= 2 * RL) acc.y = fma(wl[2 * j], p.y, acc.y);
                     }
                     ring[0][t] = acc;
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
             }
 #pragma unroll
