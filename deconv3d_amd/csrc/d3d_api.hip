@@ -110,6 +110,7 @@ struct d3d_ctx {
     int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
+    int march_one = 0;            // D3D_MARCH_ONE=2|3: one-channel-per-lane variant, TX columns
     int march_pf = 0;             // D3D_MARCH_PF=2|3: software-pipelined variant, TX columns
     // 0: tile kernel; 1: march; 2: march + the mirror symmetries the FSF has (x, and y on
     // top of x); 3: march + x symmetry only
@@ -294,6 +295,24 @@ int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, dou
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool symx = c->march_mode >= 2 && c->fsf_symx;
     const bool symxy = symx && c->fsf_symy && c->march_mode != 3;  // mode 3: x symmetry only
+    if (symxy && !FUSE && c->march_one > 0 && c->Dp % 64 == 0 && NT % c->Dp == 0) {
+        // one channel per lane: 3 (TX = 3) or 4 (TX = 2) wavefronts per SIMD
+        const int HY = c->march_hy;
+        const int S = NT / c->Dp;
+        if (c->march_one == 3) {
+            const long items = (long)((c->W + 2) / 3) * ((c->H + HY - 1) / HY);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march1<NT, FS, 3, 3>),
+                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
+                               out, HY);
+        } else {
+            const long items = (long)((c->W + 1) / 2) * ((c->H + HY - 1) / HY);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march1<NT, FS, 2, 4>),
+                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
+                               out, HY);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (uni && symxy && !FUSE && c->march_pf > 0) {
         // software-pipelined variant (next-row loads interleaved with the FMAs)
         const int HY = c->march_hy;
@@ -808,6 +827,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
             }
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
     if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
+    if (const char *e = getenv("D3D_MARCH_ONE")) c->march_one = atoi(e);
     if (const char *e = getenv("D3D_MARCH_HY")) {
         const int v = atoi(e);
         if (v >= 1) c->march_hy = v;

@@ -763,6 +763,121 @@ __global__ __launch_bounds__(NT, 2) void k_spatial_march_pf(SpatialArgs A,
     }
 }
 
+// One-channel-per-lane column march for x- and y-symmetric FSFs.  Same ring /
+// symmetry algebra as k_spatial_march<SYMX, SYMY>, but a thread owns ONE channel
+// (8-byte accesses, a spectrum spans Dp/64 wavefronts): half the registers per
+// thread, hence WPS = 3-4 wavefronts per SIMD instead of 2 to hide the bursts of
+// row loads behind other waves' FMAs.  Requires Dp to be a multiple of 64.
+template <int NT, int FS, int TX, int WPS>
+__global__ __launch_bounds__(NT, WPS) void k_spatial_march1(SpatialArgs A,
+                                                            const double *__restrict__ in,
+                                                            double *__restrict__ out, int HY) {
+    constexpr int FHH = (FS - 1) / 2;
+    constexpr int NP = FHH + 1;
+    constexpr int NR = TX + FS - 1;
+    __shared__ double s_taps[NP * NP + NP];
+    for (int i = threadIdx.x; i < NP * NP + NP; i += NT) {
+        const int k = i / NP, m = i - k * NP;
+        s_taps[i] = k < NP ? A.fsf[k * FS + m] : 0.0;
+    }
+    __syncthreads();
+
+    const int Dp = A.Dp;
+    const int S = NT / Dp;  // strips per workgroup
+    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x / Dp);
+    const int ch = threadIdx.x - s * Dp;
+    const int nxs = (A.W + TX - 1) / TX;
+    const int nys = (A.H + HY - 1) / HY;
+    int blk = blockIdx.x;
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+    }
+    const long item = (long)blk * S + s;
+    if (s >= S || item >= (long)nxs * nys) return;
+    const int ys = (int)(item / nxs);
+    const int x0 = (int)(item - (long)ys * nxs) * TX;
+    const int y0 = ys * HY;
+    const int yend = min(y0 + HY, A.H);
+    const long rowstride = (long)A.W * Dp;
+    const int dir = (A.alt_dir && (ys & 1)) ? -1 : 1;
+    const int nsteps = (yend - y0) + 2 * FHH;
+    const double *colbase = in + (long)(x0 - FHH) * Dp + ch;
+
+    double ring[FS][TX];
+#pragma unroll
+    for (int k = 0; k < FS; ++k)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[k][t] = 0.0;
+
+    int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
+    for (int step = 0; step < nsteps; ++step, r += dir) {
+        if (r >= 0 && r < A.H) {
+            double row[NR];
+            const double *base = colbase + (long)r * rowstride;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int xx = x0 - FHH + i;
+                row[i] = (xx >= 0 && xx < A.W) ? base[(long)i * Dp] : 0.0;
+            }
+            double P[TX][NP];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+#pragma unroll
+                for (int m = 0; m < FHH; ++m) P[t][m] = row[t + m] + row[t + FS - 1 - m];
+                P[t][FHH] = row[t + FHH];
+            }
+            int opq = 0;
+            asm volatile("" : "+v"(opq));  // keep the tap reads inside the loop
+            const double *taps = s_taps + opq;
+#pragma unroll
+            for (int a = 0; a <= FHH; ++a) {
+                const int ylo = r - dir * a, yhi = r + dir * a;  // rows of slots FHH-a, FHH+a
+                const bool lo_ok = (ylo >= y0) && (ylo < yend);
+                const bool hi_ok = (a > 0) && (yhi >= y0) && (yhi < yend);
+                if (lo_ok || hi_ok) {
+                    double T[TX];
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) T[t] = 0.0;
+#pragma unroll
+                    for (int m = 0; m < NP; ++m) {
+                        const double tap = taps[(FHH - a) * NP + m];
+#pragma unroll
+                        for (int t = 0; t < TX; ++t) T[t] = fma(tap, P[t][m], T[t]);
+                    }
+                    if (lo_ok) {
+#pragma unroll
+                        for (int t = 0; t < TX; ++t) ring[FHH - a][t] += T[t];
+                    }
+                    if (hi_ok) {
+#pragma unroll
+                        for (int t = 0; t < TX; ++t) ring[FHH + a][t] += T[t];
+                    }
+                }
+            }
+        }
+        const int oy0 = r - dir * FHH;  // slot 0 has received its last tap row
+        if (oy0 >= y0 && oy0 < yend) {
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const int xo = x0 + t;
+                if (xo < A.W) {
+                    const long o = (long)oy0 * rowstride + (long)xo * Dp + ch;
+                    double v = ring[0][t];
+                    if (A.data) v = A.data[o] - v;
+                    out[o] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FS - 1; ++k)
+#pragma unroll
+            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = 0.0;
+    }
+}
+
 // Any-size fallback: one output z-pair per thread, loops over all taps.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_spatial_generic(SpatialArgs A,
