@@ -24,7 +24,8 @@ SYMBOLS = [
     "d3d_set_taps", "d3d_set_data", "d3d_set_params", "d3d_get_params",
     "d3d_build_clean", "d3d_convolve", "d3d_forward", "d3d_residual",
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
-    "d3d_convolve_slots", "d3d_mh_config", "d3d_window_stats",
+    "d3d_convolve_slots", "d3d_stage_upload", "d3d_stage_convolve", "d3d_stage_download",
+    "d3d_mh_config", "d3d_window_stats",
     "d3d_mh_sweeps", "d3d_get_dlog", "d3d_colour_count",
     "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
@@ -84,6 +85,9 @@ def load():
     lib.d3d_upload_slot.argtypes = [ctx_p, C.c_int, dbl_p]
     lib.d3d_download_slot.argtypes = [ctx_p, C.c_int, dbl_p]
     lib.d3d_convolve_slots.argtypes = [ctx_p, C.c_int, C.c_int]
+    lib.d3d_stage_upload.argtypes = [ctx_p, dbl_p]
+    lib.d3d_stage_convolve.argtypes = [ctx_p]
+    lib.d3d_stage_download.argtypes = [ctx_p, dbl_p]
     lib.d3d_mh_config.argtypes = [ctx_p, dbl_p, dbl_p, dbl_p, C.c_double,
                                   C.c_uint64, C.c_int]
     lib.d3d_window_stats.argtypes = [ctx_p, C.c_int, C.c_int, dbl_p, dbl_p]
@@ -252,6 +256,18 @@ class Engine(object):
 
     def convolve_slots(self, src, dst):
         _check(self._lib.d3d_convolve_slots(self._ctx, int(src), int(dst)))
+
+    def stage_upload(self, cube):
+        cube = _c64(cube, self.shape)
+        _check(self._lib.d3d_stage_upload(self._ctx, _dp(cube)))
+
+    def stage_convolve(self):
+        _check(self._lib.d3d_stage_convolve(self._ctx))
+
+    def stage_download(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(self._lib.d3d_stage_download(self._ctx, _dp(out)))
+        return out
 
     # -- MH within Gibbs --------------------------------------------------
     def mh_config(self, min_b, max_b, jump_amp, gibbs_apriori_variance, seed=12345,

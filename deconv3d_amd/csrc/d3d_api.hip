@@ -106,10 +106,12 @@ struct d3d_ctx {
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
+    bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
+    int zmajor_hy = 32;           // output rows per strip of the z-major spatial kernel
     int march_one = 0;            // D3D_MARCH_ONE=2|3: one-channel-per-lane variant, TX columns
     int march_pf = 0;             // D3D_MARCH_PF=2|3: software-pipelined variant, TX columns
     // 0: tile kernel; 1: march; 2: march + the mirror symmetries the FSF has (x, and y on
@@ -650,6 +652,29 @@ int build_colour_lists(d3d_ctx *c) {
 
 // ---------------------------------------------------------------------------
 
+namespace {
+bool zmajor_ok(const d3d_ctx *c) {
+    if (getenv("D3D_NO_ZMAJOR")) return false;
+    if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
+    if (c->ntaps > 0 && !c->lsf_dense_ok) return false;
+    switch (c->fw) {
+        case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;
+        default: return false;
+    }
+}
+
+template <int FS>
+int launch_spatial_z(d3d_ctx *c, const double *in, double *out) {
+    const int HY = c->zmajor_hy;
+    const long items = (long)c->D * ((c->H + HY - 1) / HY) * ((c->W + 63) / 64);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_z<FS>), dim3((unsigned)((items + 3) / 4)),
+                       dim3(256), 0, c->stream, c->D, c->H, c->W, HY, (const double *)c->fsf, in,
+                       out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 int d3d_version(void) { return D3D_VERSION; }
@@ -828,6 +853,10 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
     if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
     if (const char *e = getenv("D3D_MARCH_ONE")) c->march_one = atoi(e);
+    if (const char *e = getenv("D3D_ZMAJOR_HY")) {
+        const int v = atoi(e);
+        if (v >= 1) c->zmajor_hy = v;
+    }
     if (const char *e = getenv("D3D_MARCH_HY")) {
         const int v = atoi(e);
         if (v >= 1) c->march_hy = v;
@@ -854,9 +883,10 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     c->ntaps = (int)shift.size();
     // dense form for the fused epilogue: out[k] = sum_j wl[j] v[(k + j - RL) mod N]
     c->lsf_fusable = false;
+    c->lsf_dense_ok = false;
     if (const char *e = getenv("D3D_FUSE_LSF")) c->fuse_lsf = atoi(e);
     if (const char *e = getenv("D3D_SPECTRAL_DENSE")) c->spectral_dense = atoi(e);
-    if (c->ntaps && c->N == c->Dp && c->Dp >= 4 * d3d::LSF_RL && c->HL <= 64 && 64 % c->HL == 0) {
+    if (c->ntaps && c->N == c->D && c->D >= 4 * d3d::LSF_RL) {
         std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
         bool ok = true;
         for (size_t t = 0; t < shift.size(); ++t) {
@@ -871,7 +901,9 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
             HIP_TRY(hipMemcpyAsync(c->lsf_dense, dense.data(), dense.size() * sizeof(double),
                                    hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
-            c->lsf_fusable = true;
+            c->lsf_dense_ok = true;
+            // wave-private LDS forms additionally need the spectrum within one wavefront
+            c->lsf_fusable = c->HL <= 64 && 64 % c->HL == 0;
         }
     }
     if (c->ntaps) {
@@ -1002,13 +1034,72 @@ int d3d_download_slot(d3d_ctx *c, int slot, double *cube) {
     return download_cube(c, c->slot[slot], cube);
 }
 
-int d3d_convolve(d3d_ctx *c, const double *in, double *out) {
-    NEED(c && in && out, D3D_ERR_INVALID, "NULL argument");
-    int rc = d3d_upload_slot(c, D3D_SLOT_TMP0, in);
+// ---- convolution in the reference layout (staging buffers, z-major) --------
+
+int d3d_stage_upload(d3d_ctx *c, const double *cube) {
+    NEED(c && cube, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->stage, cube, (size_t)c->D * c->HW * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_stage_download(d3d_ctx *c, double *cube) {
+    NEED(c && cube, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(cube, c->stage, (size_t)c->D * c->HW * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_stage_convolve(d3d_ctx *c) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps, D3D_ERR_STATE, "taps not set");
+    HIP_TRY(hipSetDevice(c->device));
+    if (zmajor_ok(c)) {
+        // both passes in the reference layout, lanes along x: no layout change
+        const double *src = c->stage;
+        if (c->ntaps > 0) {
+            hipLaunchKernelGGL(d3d::k_spectral_z, dim3((unsigned)((c->HW + 255) / 256)), dim3(256), 0,
+                               c->stream, c->D, c->HW, (const double *)c->lsf_dense,
+                               (const double *)c->stage, c->stage2);
+            HIP_TRY(hipGetLastError());
+            src = c->stage2;
+        }
+        double *dst = (src == c->stage) ? c->stage2 : c->stage;
+        int rc;
+        switch (c->fw) {
+            case 3: rc = launch_spatial_z<3>(c, src, dst); break;
+            case 5: rc = launch_spatial_z<5>(c, src, dst); break;
+            case 7: rc = launch_spatial_z<7>(c, src, dst); break;
+            case 9: rc = launch_spatial_z<9>(c, src, dst); break;
+            case 11: rc = launch_spatial_z<11>(c, src, dst); break;
+            case 13: rc = launch_spatial_z<13>(c, src, dst); break;
+            default: rc = launch_spatial_z<15>(c, src, dst); break;
+        }
+        if (rc) return rc;
+        if (dst != c->stage)
+            HIP_TRY(hipMemcpyAsync(c->stage, dst, (size_t)c->D * c->HW * sizeof(double),
+                                   hipMemcpyDeviceToDevice, c->stream));
+        return D3D_OK;
+    }
+    // general taps: through the spectrum-contiguous slot kernels
+    int rc = to_device_layout(c, c->stage, c->slot[D3D_SLOT_TMP0]);
     if (rc) return rc;
     rc = d3d_convolve_slots(c, D3D_SLOT_TMP0, D3D_SLOT_SIM);
     if (rc) return rc;
-    return d3d_download_slot(c, D3D_SLOT_SIM, out);
+    return to_host_layout(c, c->slot[D3D_SLOT_SIM], c->stage);
+}
+
+int d3d_convolve(d3d_ctx *c, const double *in, double *out) {
+    NEED(c && in && out, D3D_ERR_INVALID, "NULL argument");
+    int rc = d3d_stage_upload(c, in);
+    if (rc) return rc;
+    rc = d3d_stage_convolve(c);
+    if (rc) return rc;
+    return d3d_stage_download(c, out);
 }
 
 int d3d_forward(d3d_ctx *c, double *out_sim) {

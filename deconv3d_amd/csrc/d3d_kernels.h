@@ -393,6 +393,12 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
     const int dir = (SYMY && A.alt_dir && (ys & 1)) ? -1 : 1;
     const int nsteps = (yend - y0) + 2 * FHH;
     int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
+    // ROT (x+y symmetric path): the march is unrolled by FS and ring slot k of
+    // phase ph lives in physical register (ph + k) % FS -- the slot of a given
+    // output row never moves, so the FS-1 ring moves per step disappear (16 %
+    // of the kernel's fp64-rate instructions).
+    constexpr bool ROT = SYMX && SYMY && !FUSE;
+    constexpr int UNR = ROT ? FS : 1;
     // Stagger: co-resident wavefronts run the same program and fall into lock
     // step (all issue their row loads together, then all compute together).
     // Delaying every other workgroup by about half a step lets one wave's loads
@@ -403,7 +409,11 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
     unsigned long long acc_issue = 0, acc_wait = 0, acc_math = 0, acc_tail = 0, t0 = 0, t1 = 0,
                        t2 = 0, t3 = 0;
     const unsigned long long t_begin = STAMP ? stamp() : 0;
-    for (int step = 0; step < nsteps; ++step, r += dir) {
+    for (int sbase = 0; sbase < nsteps; sbase += UNR)
+#pragma unroll
+    for (int ph = 0; ph < UNR; ++ph) {
+        const int step = sbase + ph;
+        if (step >= nsteps) continue;
         if constexpr (STAMP) t0 = stamp();
         if (r >= 0 && r < A.H) {
             const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
@@ -483,15 +493,15 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                         if (lo_ok) {
 #pragma unroll
                             for (int t = 0; t < TX; ++t) {
-                                ring[FHH - a][t].x += T[t].x;
-                                ring[FHH - a][t].y += T[t].y;
+                                ring[ROT ? (ph + FHH - a) % FS : FHH - a][t].x += T[t].x;
+                                ring[ROT ? (ph + FHH - a) % FS : FHH - a][t].y += T[t].y;
                             }
                         }
                         if (hi_ok) {
 #pragma unroll
                             for (int t = 0; t < TX; ++t) {
-                                ring[FHH + a][t].x += T[t].x;
-                                ring[FHH + a][t].y += T[t].y;
+                                ring[ROT ? (ph + FHH + a) % FS : FHH + a][t].x += T[t].x;
+                                ring[ROT ? (ph + FHH + a) % FS : FHH + a][t].y += T[t].y;
                             }
                         }
                     }
@@ -544,7 +554,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
 #pragma unroll
                 for (int t = 0; t < TX; ++t) {
                     double *bt = buf + t * (N + 2 * RL);
-                    const double2 v = ring[0][t];
+                    const double2 v = ring[ROT ? ph % FS : 0][t];
                     *reinterpret_cast<double2 *>(bt + RL + 2 * zl) = v;
                     if (2 * zl < RL) *reinterpret_cast<double2 *>(bt + N + RL + 2 * zl) = v;
                     if (2 * zl >= N - RL) *reinterpret_cast<double2 *>(bt + RL + 2 * zl - N) = v;
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                         if (2 * j - 1 >= 0) acc.y = fma(wl[2 * j - 1], p.x, acc.y);
                         if (2 * j <= 2 * RL) acc.y = fma(wl[2 * j], p.y, acc.y);
                     }
-                    ring[0][t] = acc;
+                    ring[ROT ? ph % FS : 0][t] = acc;
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_wave_barrier();
@@ -581,7 +591,7 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                 const int xo = x0 + t;
                 if (xo < A.W) {
                     const long o = (long)oy0 * rowstride + (long)xo * A.Dp + 2 * zl;
-                    double2 v = ring[0][t];
+                    double2 v = ring[ROT ? ph % FS : 0][t];
                     if (A.data) {
                         const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
                         v.x = d.x - v.x;
@@ -591,12 +601,19 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
                 }
             }
         }
+        if constexpr (ROT) {
+            // the finished slot becomes the newest one of the next phase
 #pragma unroll
-        for (int k = 0; k < FS - 1; ++k)
+            for (int t = 0; t < TX; ++t) ring[ph % FS][t] = make_double2(0.0, 0.0);
+        } else {
 #pragma unroll
-            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+            for (int k = 0; k < FS - 1; ++k)
 #pragma unroll
-        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+                for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+        }
+        r += dir;
         if constexpr (STAMP) acc_tail += stamp() - t3;
     }
     if constexpr (STAMP) {
@@ -910,6 +927,157 @@ __global__ __launch_bounds__(NT) void k_spatial_generic(SpatialArgs A,
         acc.y = d.y - acc.y;
     }
     *reinterpret_cast<double2 *>(out + o) = acc;
+}
+
+// ------------------------------------------------------------------------- //
+// z-major convolution kernels: the cube in the REFERENCE layout (D, H, W),     //
+// x fastest (lib/run.py:146-149), lanes along x.  d3d_convolve works there      //
+// without any layout change.                                                   //
+// ------------------------------------------------------------------------- //
+
+// Spectral pass, z-major: a thread owns one spaxel (consecutive lanes =
+// consecutive x: every access 8 B/lane contiguous) and marches along z with the
+// 2*LSF_RL+1 channels around the current one in registers:
+//   out[k] = sum_j wl[j] * in[(k + j - RL) mod D]       (D a power of two)
+// The window rotates at compile time (the march is unrolled by its length).
+__global__ __launch_bounds__(256) void k_spectral_z(int D, long HW, const double *__restrict__ wl,
+                                                    const double *__restrict__ in,
+                                                    double *__restrict__ out) {
+    constexpr int RL = LSF_RL, NW = 2 * LSF_RL + 1;
+    const long sp = (long)blockIdx.x * 256 + threadIdx.x;
+    if (sp >= HW) return;
+    double w[NW], t[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        t[j] = wl[j];
+        w[j] = in[(long)((j - RL) & (D - 1)) * HW + sp];  // channels -RL .. +RL around 0
+    }
+    // invariant at output channel k (k = base + ph): w[(ph + j) % NW] = in[k + j - RL]
+    for (int base = 0; base < D; base += NW) {
+#pragma unroll
+        for (int ph = 0; ph < NW; ++ph) {
+            const int k = base + ph;
+            if (k < D) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NW; ++j) acc = fma(t[j], w[(ph + j) % NW], acc);
+                out[(long)k * HW + sp] = acc;
+                // slot of in[k - RL] is free: load in[k + RL + 1] for the next channel
+                w[ph % NW] = in[(long)((k + RL + 1) & (D - 1)) * HW + sp];
+            }
+        }
+    }
+}
+
+// Spatial pass, z-major, for FSFs that are mirror-symmetric in x and y.  A
+// wavefront owns 64 consecutive columns of one channel image and marches down HY
+// rows; each input row segment (64 + FS-1 values) goes through a wave-private
+// LDS row, every lane folds its FS neighbours (x symmetry), forms the FHH+1
+// tap-row dot products once and adds them to the two ring slots FHH-a / FHH+a
+// (y symmetry).  The ring (FS doubles per thread) rotates at compile time.  An
+// input value is loaded once per tile (plus the halo), the kernel needs ~60
+// VGPRs: 8 wavefronts per SIMD, HBM-bound.
+template <int FS>
+__global__ __launch_bounds__(256) void k_spatial_z(int D, int H, int W, int HY,
+                                                   const double *__restrict__ fsf,
+                                                   const double *__restrict__ in,
+                                                   double *__restrict__ out) {
+    constexpr int FHH = (FS - 1) / 2, NP = FHH + 1;
+    constexpr int ROWLEN = 64 + FS - 1;
+    __shared__ double s_row[4][ROWLEN + 1];
+    // wave index made scalar: every row/strip test below is then a scalar branch
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nxt = (W + 63) / 64, nys = (H + HY - 1) / HY;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)D * nys * nxt) return;
+    const int z = (int)(item / ((long)nys * nxt));
+    const int rem = (int)(item - (long)z * nys * nxt);
+    const int ys = rem / nxt, xt = rem - ys * nxt;
+    const int x = xt * 64 + lane;
+    const int y0 = ys * HY, yend = min(y0 + HY, H);
+    const double *img = in + (long)z * H * W;
+    double *oimg = out + (long)z * H * W;
+    double *rowbuf = s_row[wave];
+
+    double tap[NP][NP];  // rows 0..FHH, columns 0..FHH of the FSF (the rest by symmetry)
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) tap[k][m] = fsf[k * FS + m];
+
+    double ring[FS];
+#pragma unroll
+    for (int k = 0; k < FS; ++k) ring[k] = 0.0;
+
+    const int nsteps = (yend - y0) + 2 * FHH;
+    // one row segment [xt*64 - FHH, xt*64 + 63 + FHH]: lane l holds element l,
+    // lanes < FS-1 also element l + 64 (zero outside the image / the cube)
+    const int xa = xt * 64 - FHH + lane, xb = xa + 64;
+    const bool a_in = xa >= 0 && xa < W, b_in = lane < FS - 1 && xb >= 0 && xb < W;
+    auto fetch = [&](int r, double &va, double &vb) {
+        va = 0.0;
+        vb = 0.0;
+        if (r >= 0 && r < H) {
+            if (a_in) va = img[(long)r * W + xa];
+            if (b_in) vb = img[(long)r * W + xb];
+        }
+    };
+    double va, vb;
+    fetch(y0 - FHH, va, vb);
+    // step s reads input row r = y0 - FHH + s.  The slot of output row
+    // (r - FHH + k) is (ph + k) % FS at phase ph = s % FS: constant per output
+    // row, so the ring never moves (the march is unrolled by FS).
+    for (int base = 0; base < nsteps; base += FS) {
+#pragma unroll
+        for (int ph = 0; ph < FS; ++ph) {
+            const int step = base + ph;
+            if (step < nsteps) {
+                const int r = y0 - FHH + step;
+                // this row through the wave-private LDS row; next row's loads fly
+                rowbuf[lane] = va;
+                if (lane < FS - 1) rowbuf[lane + 64] = vb;
+                __builtin_amdgcn_wave_barrier();
+                double P[NP];
+#pragma unroll
+                for (int m = 0; m < FHH; ++m) P[m] = rowbuf[lane + m] + rowbuf[lane + FS - 1 - m];
+                P[FHH] = rowbuf[lane + FHH];
+                __builtin_amdgcn_wave_barrier();
+                fetch(r + 1, va, vb);
+                if (r >= 0 && r < H) {
+                    if ((r - FHH >= y0) && (r + FHH < yend)) {
+                        // steady state: every slot is live, no range tests
+#pragma unroll
+                        for (int a = 0; a <= FHH; ++a) {
+                            double T = 0.0;
+#pragma unroll
+                            for (int m = 0; m < NP; ++m) T = fma(tap[FHH - a][m], P[m], T);
+                            ring[(ph + FHH - a) % FS] += T;
+                            if (a > 0) ring[(ph + FHH + a) % FS] += T;
+                        }
+                    } else {
+#pragma unroll
+                        for (int a = 0; a <= FHH; ++a) {
+                            const int ylo = r - a, yhi = r + a;
+                            const bool lo_ok = ylo >= y0 && ylo < yend;
+                            const bool hi_ok = a > 0 && yhi >= y0 && yhi < yend;
+                            if (lo_ok || hi_ok) {
+                                double T = 0.0;
+#pragma unroll
+                                for (int m = 0; m < NP; ++m) T = fma(tap[FHH - a][m], P[m], T);
+                                // output row r-a sits in slot k = FHH - a, row r+a in k = FHH + a
+                                if (lo_ok) ring[(ph + FHH - a) % FS] += T;
+                                if (hi_ok) ring[(ph + FHH + a) % FS] += T;
+                            }
+                        }
+                    }
+                }
+                const int oy0 = r - FHH;  // slot k = 0 is complete
+                if (oy0 >= y0 && oy0 < yend && x < W) oimg[(long)oy0 * W + x] = ring[ph % FS];
+                ring[ph % FS] = 0.0;  // becomes slot k = FS-1 of the next step
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------- //

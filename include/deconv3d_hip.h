@@ -116,6 +116,15 @@ int d3d_residual(d3d_ctx *ctx, double *out_err);
  * lib/run.py:423 summed per spectrum) and its total.  Either may be NULL. */
 int d3d_chi2_map(d3d_ctx *ctx, double *out_hw, double *total);
 
+/* The same convolution on a cube that stays on the device in the REFERENCE
+ * layout (D,H,W) (lib/run.py:146-149): upload once, convolve in place any
+ * number of times, download.  d3d_convolve == upload + convolve + download.
+ * With mirror-symmetric FSFs and a compact LSF both passes run in that layout
+ * (lanes along x), otherwise through the spectrum-contiguous slot kernels. */
+int d3d_stage_upload(d3d_ctx *ctx, const double *cube);
+int d3d_stage_convolve(d3d_ctx *ctx);
+int d3d_stage_download(d3d_ctx *ctx, double *cube);
+
 /* Device-resident variants (no host traffic; used by bench.py). */
 int d3d_upload_slot(d3d_ctx *ctx, int slot, const double *cube);
 int d3d_download_slot(d3d_ctx *ctx, int slot, double *cube);
