@@ -269,10 +269,10 @@ def main():
     for _ in range(args.conv_iters):
         eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
     slots_ms = eng.timer_stop() / max(args.conv_iters, 1)
-    roofline_conv = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
-                               "k_spatial_z")
-    roofline_conv_slots = conv_entry(slots_ms, "k_spectral_dense + k_spatial_march (slot layout)",
-                                     "k_spatial_march")
+    roofline_conv = conv_entry(slots_ms, "k_spectral_dense + k_spatial_march (slot layout)",
+                               "k_spatial_march")
+    roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
+                                          "k_spatial_z")
 
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)",
@@ -295,7 +295,7 @@ def main():
         "acceptance": round(accepted / float(args.steps * n_spaxels), 4),
         "roofline": roofline,
         "roofline_conv": roofline_conv,
-        "roofline_conv_slots": roofline_conv_slots,
+        "roofline_conv_ref_layout": roofline_conv_ref_layout,
     }
 
     if rank == 0 and not args.no_cpu:

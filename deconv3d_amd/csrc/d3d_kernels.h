@@ -1046,14 +1046,19 @@ __global__ __launch_bounds__(256) void k_spatial_z(int D, int H, int W, int HY,
                 fetch(r + 1, va, vb);
                 if (r >= 0 && r < H) {
                     if ((r - FHH >= y0) && (r + FHH < yend)) {
-                        // steady state: every slot is live, no range tests
+                        // steady state: every slot is live, no range tests; the
+                        // FHH+1 dot products advance together (independent chains)
+                        double T[NP];
+#pragma unroll
+                        for (int a = 0; a <= FHH; ++a) T[a] = tap[FHH - a][0] * P[0];
+#pragma unroll
+                        for (int m = 1; m < NP; ++m)
+#pragma unroll
+                            for (int a = 0; a <= FHH; ++a) T[a] = fma(tap[FHH - a][m], P[m], T[a]);
 #pragma unroll
                         for (int a = 0; a <= FHH; ++a) {
-                            double T = 0.0;
-#pragma unroll
-                            for (int m = 0; m < NP; ++m) T = fma(tap[FHH - a][m], P[m], T);
-                            ring[(ph + FHH - a) % FS] += T;
-                            if (a > 0) ring[(ph + FHH + a) % FS] += T;
+                            ring[(ph + FHH - a) % FS] += T[a];
+                            if (a > 0) ring[(ph + FHH + a) % FS] += T[a];
                         }
                     } else {
 #pragma unroll
