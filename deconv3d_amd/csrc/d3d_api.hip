@@ -251,6 +251,7 @@ int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double
     return 0;
 }
 
+#ifdef D3D_EXPERIMENTS
 // Diagnostic build (D3D_STAMP=1): the xy-symmetric march kernel with in-kernel
 // s_memtime stamps; prints the per-phase cycle shares of a march step to stderr.
 template <int NT, int FS, int TX>
@@ -291,12 +292,15 @@ int launch_march_stamped(d3d_ctx *c, d3d::SpatialArgs A, const double *in, doubl
     return 0;
 }
 
+#endif  // D3D_EXPERIMENTS
+
 template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool symx = c->march_mode >= 2 && c->fsf_symx;
     const bool symxy = symx && c->fsf_symy && c->march_mode != 3;  // mode 3: x symmetry only
+#ifdef D3D_EXPERIMENTS
     if (symxy && !FUSE && c->march_one > 0 && c->Dp % 64 == 0 && NT % c->Dp == 0) {
         // one channel per lane: 3 (TX = 3) or 4 (TX = 2) wavefronts per SIMD
         const int HY = c->march_hy;
@@ -333,10 +337,13 @@ int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, dou
         HIP_TRY(hipGetLastError());
         return 0;
     }
+#endif
     if (uni) {
+#ifdef D3D_EXPERIMENTS
         if constexpr (FS == 11 && !FUSE && NT == 256) {
             if (symxy && getenv("D3D_STAMP")) return launch_march_stamped<NT, FS, TX>(c, A, in, out);
         }
+#endif
         if (symxy) return launch_march<NT, FS, TX, true, true, FUSE, true>(c, A, in, out);
         if (symx) return launch_march<NT, FS, TX, true, true, FUSE, false>(c, A, in, out);
         return launch_march<NT, FS, TX, false, true, FUSE, false>(c, A, in, out);
@@ -381,13 +388,19 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
     A.dbg = nullptr;
     A.stagger = getenv("D3D_STAGGER") ? atoi(getenv("D3D_STAGGER")) : 0;
+    // (the march kernels are built for 256-thread groups only: D <= 512; deeper
+    // cubes use the tile kernel below)
+    if constexpr (NT == 256)
     if (c->march_mode > 0 && c->fh == c->fw) {
         bool done = false;
         int rc;
+#ifdef D3D_EXPERIMENTS
         if (fuse_lsf) {
             A.lsf_dense = c->lsf_dense;
             rc = launch_march_any<NT, true>(c, A, in, out, &done);
-        } else {
+        } else
+#endif
+        {
             rc = launch_march_any<NT, false>(c, A, in, out, &done);
         }
         if (done) return rc;
@@ -415,6 +428,9 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
 
 // True when the spatial pass can apply the LSF itself (fused epilogue).
 bool can_fuse_lsf(const d3d_ctx *c) {
+#ifndef D3D_EXPERIMENTS
+    return false;  // the fused epilogue is an experiment (slower than the streaming LSF pass)
+#endif
     if (!c->fuse_lsf || !c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;

@@ -828,7 +828,13 @@ __global__ __launch_bounds__(NT, WPS) void k_spatial_march1(SpatialArgs A,
         for (int t = 0; t < TX; ++t) ring[k][t] = 0.0;
 
     int r = dir > 0 ? y0 - FHH : yend - 1 + FHH;
-    for (int step = 0; step < nsteps; ++step, r += dir) {
+    // the march is unrolled by FS: ring slot k of phase ph lives in physical
+    // register (ph + k) % FS, so the ring never moves
+    for (int sbase = 0; sbase < nsteps; sbase += FS)
+#pragma unroll
+    for (int ph = 0; ph < FS; ++ph) {
+        const int step = sbase + ph;
+        if (step >= nsteps) continue;
         if (r >= 0 && r < A.H) {
             double row[NR];
             const double *base = colbase + (long)r * rowstride;
@@ -864,11 +870,11 @@ __global__ __launch_bounds__(NT, WPS) void k_spatial_march1(SpatialArgs A,
                     }
                     if (lo_ok) {
 #pragma unroll
-                        for (int t = 0; t < TX; ++t) ring[FHH - a][t] += T[t];
+                        for (int t = 0; t < TX; ++t) ring[(ph + FHH - a) % FS][t] += T[t];
                     }
                     if (hi_ok) {
 #pragma unroll
-                        for (int t = 0; t < TX; ++t) ring[FHH + a][t] += T[t];
+                        for (int t = 0; t < TX; ++t) ring[(ph + FHH + a) % FS][t] += T[t];
                     }
                 }
             }
@@ -880,18 +886,15 @@ __global__ __launch_bounds__(NT, WPS) void k_spatial_march1(SpatialArgs A,
                 const int xo = x0 + t;
                 if (xo < A.W) {
                     const long o = (long)oy0 * rowstride + (long)xo * Dp + ch;
-                    double v = ring[0][t];
+                    double v = ring[ph % FS][t];
                     if (A.data) v = A.data[o] - v;
                     out[o] = v;
                 }
             }
         }
 #pragma unroll
-        for (int k = 0; k < FS - 1; ++k)
-#pragma unroll
-            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
-#pragma unroll
-        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = 0.0;
+        for (int t = 0; t < TX; ++t) ring[ph % FS][t] = 0.0;  // newest slot of the next phase
+        r += dir;
     }
 }
 
