@@ -113,6 +113,27 @@ def cpu_baseline(data, var, mask, fsf, lsf, params, min_b, max_b, err, budget_s)
     return n / dt, n, dt
 
 
+def cpu_baseline_faithful(budget_s):
+    """BASELINE.md B-ref: the reference-faithful update (full-cube temporaries
+    and the (H,W,D,H,W) contributions array, lib/run.py:285-288, 367-519) on
+    config 1 (32x16x16, Gaussian 9x9) -- the only BASELINE shape where that array
+    (16.8 MB) is harmless; at 300x300x128 it would be 8.3 TB."""
+    from oracle import deconv3d_oracle as O
+    D, H, W = 32, 16, 16
+    fsf = O.gaussian_fsf_image(3.0)
+    lsf = O.gaussian_lsf_vector(D, 0.9088)
+    data, var, mask, truth, init, mn, mx = O.synthetic_case(D, H, W, fsf, lsf)
+    st = O.RefFaithfulState(data, var, mask, fsf, lsf, init, mn, mx)
+    n = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for (y, x) in O.spaxel_iterator(mask):          # the reference's row-major scan
+            O.ref_faithful_update(st, y, x, 1 + n // (H * W))
+            n += 1
+    dt = time.perf_counter() - t0
+    return n / dt, n, dt
+
+
 def measured_traffic(kernel_prefix, workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
@@ -310,6 +331,11 @@ def main():
                       "cannot run)" % (n, args.workload, secs, H * W * D * H * W * 8 / 1e12),
             "host_cores_visible": cores, "numpy": np.__version__}
         out["vs_cpu"] = round(value / rate, 1)
+        frate, fn, fsecs = cpu_baseline_faithful(min(3.0, args.cpu_seconds))
+        out["cpu_baseline_faithful"] = {
+            "value": round(frate, 2), "unit": "spaxel-updates/s", "cores": 1, "kind": "port",
+            "sample": "%d updates in %.1f s of the reference-faithful form (full-cube temporaries + "
+                      "contributions array) on config 1, 32x16x16 / 9x9" % (fn, fsecs)}
 
     eng.close()
     if dist is not None:
