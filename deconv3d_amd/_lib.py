@@ -26,7 +26,7 @@ SYMBOLS = [
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
     "d3d_convolve_slots", "d3d_stage_upload", "d3d_stage_convolve", "d3d_stage_download",
     "d3d_mh_config", "d3d_window_stats",
-    "d3d_mh_sweeps", "d3d_get_dlog", "d3d_colour_count",
+    "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_colour_count",
     "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
 
@@ -94,6 +94,8 @@ def load():
     lib.d3d_mh_sweeps.argtypes = [ctx_p, C.c_int, C.c_int, C.c_int, dbl_p,
                                   dbl_p, C.POINTER(C.c_int64)]
     lib.d3d_get_dlog.argtypes = [ctx_p, dbl_p]
+    lib.d3d_mh_colour_lines.argtypes = [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_int), dbl_p,
+                                        dbl_p, C.c_int, dbl_p]
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
     lib.d3d_set_tile.argtypes = [ctx_p] + [C.c_int] * 7
     lib.d3d_mh_colour.argtypes = [ctx_p, C.c_int, C.c_int]
@@ -309,6 +311,22 @@ class Engine(object):
                                        int(keep_one_in), chain_p, dlog_p,
                                        C.byref(acc)))
         return acc.value
+
+    def mh_colour_lines(self, sweep, spaxels, in3, lines, gibbs=True):
+        """One colour class with host-evaluated unit lines (custom LineModel).
+        spaxels [n] local indices, in3 [n,3] = (amplitude, oob, log u),
+        lines [n,2,D] = (current, proposed).  Returns [n,3] = (accepted,
+        amplitude, delta)."""
+        spaxels = np.ascontiguousarray(spaxels, dtype=np.int32)
+        n = spaxels.shape[0]
+        in3 = _c64(in3, (n, 3))
+        lines = _c64(lines, (n, 2, self.shape[0]))
+        out = np.empty((n, 3), dtype=np.float64)
+        if n:
+            _check(self._lib.d3d_mh_colour_lines(
+                self._ctx, int(sweep), n, spaxels.ctypes.data_as(C.POINTER(C.c_int)),
+                _dp(in3), _dp(lines), 1 if gibbs else 0, _dp(out)))
+        return out
 
     def get_dlog(self):
         out = np.empty(self.shape[1:], dtype=np.float64)

@@ -103,6 +103,8 @@ struct d3d_ctx {
     double *prev = nullptr;          // [HW*3] parameters before each spaxel's last update
     double *recbuf = nullptr;        // [HW*8] staging of update records
     int *idxbuf = nullptr;           // [HW] staging of spaxel lists
+    double *extbuf = nullptr;        // external-lines staging: [cap][6 + 2D] doubles
+    size_t ext_cap = 0;              // spaxels per d3d_mh_colour_lines call it can hold
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
@@ -499,6 +501,11 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.prev_cy = c->pend_cy;
     P.prev_cx = c->pend_cx;
     P.slots_x = c->slots_x;
+    P.ext_idx = nullptr;
+    P.ext_in = nullptr;
+    P.ext_lines = nullptr;
+    P.ext_out = nullptr;
+    P.ext_gibbs = 1;
     P.probe = 0;
     P.probe_sp = 0;
     P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
@@ -808,7 +815,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1],
-                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf};
+                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1358,6 +1365,53 @@ int d3d_apply_updates(d3d_ctx *c, int n, const double *records) {
                            dim3(1024), lds, c->stream, P, (const double *)c->recbuf, n);
     }
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_mh_colour_lines(d3d_ctx *c, int sweep, int n, const int *spaxels, const double *in3,
+                        const double *lines, int gibbs, double *out3) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(n >= 0 && sweep >= 0, D3D_ERR_INVALID, "bad count / sweep");
+    if (n == 0) return D3D_OK;
+    NEED(spaxels && in3 && lines && out3, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_taps && c->have_data && c->have_cfg && c->err_valid, D3D_ERR_STATE,
+         "taps/data/mh_config/residual not set");
+    NEED(n <= c->HW, D3D_ERR_INVALID, "too many spaxels");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = flush_pending(c)) return rc;
+    const size_t per = 6 + 2 * (size_t)c->D;
+    if ((size_t)n > c->ext_cap) {
+        if (c->extbuf) (void)hipFree(c->extbuf);
+        c->extbuf = nullptr;
+        c->ext_cap = 0;
+        HIP_TRY(hipMalloc(&c->extbuf, (size_t)n * per * sizeof(double)));
+        c->ext_cap = (size_t)n;
+    }
+    double *d_in = c->extbuf;                      // [n*3]
+    double *d_out = d_in + (size_t)n * 3;          // [n*3]
+    double *d_lines = d_out + (size_t)n * 3;       // [n*2*D]
+    HIP_TRY(hipMemcpyAsync(c->idxbuf, spaxels, (size_t)n * sizeof(int), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, in3, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice,
+                           c->stream));
+    HIP_TRY(hipMemcpyAsync(d_lines, lines, (size_t)n * 2 * c->D * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    P.ext_idx = c->idxbuf;
+    P.ext_in = d_in;
+    P.ext_lines = d_lines;
+    P.ext_out = d_out;
+    P.ext_gibbs = gibbs ? 1 : 0;
+    P.prev = nullptr;
+    const int saved_maxit = c->mh_maxit;
+    c->mh_maxit = 0;  // re-read variant: any window size
+    int rc = launch_mh(c, P, (unsigned)n, (uint32_t)sweep);
+    c->mh_maxit = saved_maxit;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(out3, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost,
+                           c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D3D_OK;
 }

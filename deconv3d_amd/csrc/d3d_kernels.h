@@ -1187,6 +1187,17 @@ struct MHArgs {
     double *Gcur;         // [slots][Dp] this launch's updates
     int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
     int slots_x;          // slot(y,x) = (y/fh)*slots_x + x/fw
+    // external-lines mode (d3d_mh_colour_lines: a python LineModel evaluated on
+    // the host): per workgroup i the spaxel ext_idx[i], its current amplitude
+    // ext_in[i*3+0] (1 when the model has no Gibbs amplitude), an out-of-bounds
+    // flag ext_in[i*3+1], log(u) of the acceptance test ext_in[i*3+2], and the
+    // unit lines ext_lines[(i*2+0)*D ..] (current) / [(i*2+1)*D ..] (proposed).
+    // Results {accepted, amplitude, delta} go to ext_out[i*3 ..].
+    const int *ext_idx;
+    const double *ext_in;
+    const double *ext_lines;
+    double *ext_out;
+    int ext_gibbs;  // 1: draw the amplitude (lib/run.py:456-519), 0: model without Gibbs
     // probe mode (d3d_window_stats): evaluate probe_p at spaxel probe_sp, write
     // 5 doubles to probe_out, modify nothing.
     int probe;
@@ -1244,11 +1255,23 @@ struct MHProposal {
 // Every calling thread computes the same numbers.
 __device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32_t sweep) {
     MHProposal q;
+    const int ly = sp / P.W, lx = sp - ly * P.W;
+    q.gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
+    if (P.ext_lines) {
+        // proposal made on the host: only the amplitude, the bounds verdict and
+        // log(u) come in; the lines themselves are read by the caller
+        const double *in3 = P.ext_in + (long)blockIdx.x * 3;
+        q.a_old = in3[0];
+        q.c_old = q.w_old = 0.0;
+        q.pn[0] = q.a_old;
+        q.pn[1] = q.pn[2] = 0.0;
+        q.oob = in3[1] != 0.0;
+        q.log_u = in3[2];
+        return q;
+    }
     q.a_old = P.params[(long)sp * 3 + 0];
     q.c_old = P.params[(long)sp * 3 + 1];
     q.w_old = P.params[(long)sp * 3 + 2];
-    const int ly = sp / P.W, lx = sp - ly * P.W;
-    q.gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
     double u_acc = 0.5;
     if (P.probe) {
         q.pn[0] = P.probe_p[0];
@@ -1368,15 +1391,28 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
     const double s_eu = accept ? tot[6] : tot[4];
 
     // ---- Gibbs draw of the amplitude (lib/run.py:456-499) ------------------
-    const double ro = P.ra / (1.0 + P.ra * s_ee);
-    const double mu = ro * s_eu;
-    uint32_t blk = BLK_GIBBS;
-    const double r =
-        truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep, &blk);
+    double r;
+    if (P.ext_lines && !P.ext_gibbs) {
+        r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
+    } else {
+        const double ro = P.ra / (1.0 + P.ra * s_ee);
+        const double mu = ro * s_eu;
+        uint32_t blk = BLK_GIBBS;
+        r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep, &blk);
+    }
 
     // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
     *Gz_out = (ch < D) ? residual_coeff(q.a_old, EO, r, Eend) : 0.0;
     if (ch == 0) {
+        if (P.ext_lines) {
+            double *o3 = P.ext_out + (long)blockIdx.x * 3;
+            o3[0] = accept ? 1.0 : 0.0;
+            o3[1] = r;
+            o3[2] = delta;
+            P.dlog[sp] = delta;
+            if (accept) atomicAdd(P.accepted, 1ULL);
+            return true;
+        }
         if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
             P.prev[(long)sp * 3 + 0] = q.a_old;
             P.prev[(long)sp * 3 + 1] = q.c_old;
@@ -1400,8 +1436,14 @@ __device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, in
     const int tid = threadIdx.x;
     const MHProposal q = mh_propose(P, sp, sweep);
     if (tid < P.N) {
-        S.gO[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.c_old, q.w_old) : 0.0;
-        S.gN[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.pn[1], q.pn[2]) : 0.0;
+        if (P.ext_lines) {
+            const double *L = P.ext_lines + (long)blockIdx.x * 2 * P.D;
+            S.gO[tid] = (tid < P.D) ? L[tid] : 0.0;
+            S.gN[tid] = (tid < P.D) ? L[P.D + tid] : 0.0;
+        } else {
+            S.gO[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.c_old, q.w_old) : 0.0;
+            S.gN[tid] = (tid < P.D) ? unit_gaussian((double)tid, q.pn[1], q.pn[2]) : 0.0;
+        }
     }
     __syncthreads();
     double EO, EN;
@@ -1437,6 +1479,8 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     int sp;
     if (P.probe) {
         sp = P.probe_sp;
+    } else if (P.ext_lines) {
+        sp = P.ext_idx[blockIdx.x];
     } else {
         const int4 ent = P.spx[blockIdx.x];
         sp = ent.x * P.W + ent.y;

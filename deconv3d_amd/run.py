@@ -20,7 +20,11 @@ Differences from the reference, all deliberate:
   * chain / likelihoods are NaN-initialised instead of uninitialised memory;
   * the user's mask is copied, not mutated; zero variances become 1e12 for
     ndarray input too; NaN voxels get zero weight in the Gibbs sums as well;
-  * 1-D ``initial_parameters`` are broadcast as the docstring promises.
+  * 1-D ``initial_parameters`` are broadcast as the docstring promises;
+  * ``SingleGaussianLineModel`` (and subclasses that only change names/bounds)
+    is evaluated on the device; any other ``LineModel`` plugin is evaluated on
+    the host per colour class (host_model.py) with the same device kernels for
+    everything else -- correct, but python-speed.
 """
 from __future__ import annotations
 
@@ -163,7 +167,7 @@ class Run:
             self.model = model()
             if not isinstance(self.model, LineModel):
                 raise TypeError("Provided model is not a LineModel")
-        self._check_model_is_on_device()
+        self._host_model = not self._model_is_on_device()
         min_boundaries = np.array(self.model.min_boundaries(self), dtype=np.float64)
         max_boundaries = np.array(self.model.max_boundaries(self), dtype=np.float64)
         names = self.model.parameters()
@@ -174,9 +178,12 @@ class Run:
         parameters_count = len(names)
         jumping_amplitude = np.ones(parameters_count) * np.array(jump_amplitude)
         gpi = self.model.gibbs_parameter_index()
-        jumping_amplitude[gpi] = 0
-        if gibbs_apriori_variance is None:
-            gibbs_apriori_variance = float(max_boundaries[gpi] ** 2)
+        if gpi is not None:                                   # lib/run.py:255-265
+            jumping_amplitude[gpi] = 0
+            if gibbs_apriori_variance is None:
+                gibbs_apriori_variance = float(max_boundaries[gpi] ** 2)
+        elif gibbs_apriori_variance is None:
+            gibbs_apriori_variance = 1.0
         self.min_boundaries = min_boundaries
         self.max_boundaries = max_boundaries
         self.jumping_amplitude = jumping_amplitude
@@ -217,12 +224,23 @@ class Run:
         self.engine = _lib.Engine(cube_shape, self.fsf.shape, device=device)
         self.engine.set_taps(self.fsf, self.lsf)
         self.engine.set_data(self.cube.data, self.variance_cube, mask=self.mask)
-        self.engine.set_params(self.chain[0])
-        self.engine.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
-                              gibbs_apriori_variance, seed=self.seed,
-                              refresh_every=refresh_every)
+        host_chain = None
+        if self._host_model:
+            from .host_model import HostModelChain
+            self.logger.info("Line model %s is evaluated on the host (slower path)."
+                             % type(self.model).__name__)
+            host_chain = HostModelChain(self, self.engine, self.chain[0], min_boundaries,
+                                        max_boundaries, jumping_amplitude, gibbs_apriori_variance,
+                                        self.seed, refresh_every)
+            self._host_chain = host_chain
+        else:
+            self.engine.set_params(self.chain[0])
+            self.engine.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
+                                  gibbs_apriori_variance, seed=self.seed,
+                                  refresh_every=refresh_every)
         self.logger.info("Iteration #1")
-        self.engine.residual(fetch=False)          # lib/run.py:317-334
+        if host_chain is None:
+            self.engine.residual(fetch=False)          # lib/run.py:317-334
 
         # ---- MH within Gibbs loop (lib/run.py:336-537) -------------------------
         cur_iteration = 1
@@ -232,6 +250,8 @@ class Run:
         # batched per device call here (at most up to the next saved sweep)
         if sweeps_per_call is None:
             sweeps_per_call = max(1, min(int(keep_one_in), 64))
+        if host_chain is not None:
+            sweeps_per_call = 1
         self.iterations_done = 1
         while cur_iteration < max_iterations and \
                 (cur_acceptance_rate > min_acceptance_rate or cur_acceptance_rate == 0.):
@@ -241,8 +261,16 @@ class Run:
             n = min(sweeps_per_call, max_iterations - cur_iteration)
             self.logger.info("Iteration #%d / %d, %2.0f%%" %
                              (cur_iteration + 1, max_iterations, 100 * cur_acceptance_rate))
-            accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
-                                                    self.chain, likelihoods)
+            if host_chain is not None:
+                save = cur_iteration % keep_one_in == 0
+                slot = cur_iteration // keep_one_in
+                accepted_count += host_chain.sweep(cur_iteration,
+                                                   likelihoods[slot] if save else None)
+                if save:
+                    self.chain[slot] = host_chain.params
+            else:
+                accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
+                                                        self.chain, likelihoods)
             before = cur_iteration
             cur_iteration += n
             # write_every: documented (lib/run.py:89-92) but never used by the
@@ -263,26 +291,25 @@ class Run:
 
     # ------------------------------------------------------------------------
 
-    def _check_model_is_on_device(self):
-        """The HIP kernels evaluate SingleGaussianLineModel; subclasses may
-        change names/bounds but not the curve or the Gibbs index."""
+    def _model_is_on_device(self):
+        """The HIP kernels evaluate SingleGaussianLineModel themselves (subclasses
+        may change names/bounds but not the curve or the Gibbs index); any other
+        LineModel plugin is evaluated on the host (host_model.HostModelChain):
+        same device kernels for LSF, window statistics, accept, Gibbs draw and
+        residual, but python-speed proposals and modelize() calls."""
         m = self.model
-        ok = (isinstance(m, SingleGaussianLineModel)
-              and type(m).modelize is SingleGaussianLineModel.modelize
-              and type(m).gaussian is SingleGaussianLineModel.gaussian
-              and type(m).post_jump is LineModel.post_jump
-              and m.gibbs_parameter_index() == 0
-              and len(m.parameters()) == 3)
-        if not ok:
-            raise NotImplementedError(
-                "deconv3d_amd evaluates the line model on the GPU and implements "
-                "SingleGaussianLineModel (optionally with overridden boundaries); custom "
-                "modelize()/post_jump()/gibbs index are not supported yet.")
+        return (isinstance(m, SingleGaussianLineModel)
+                and type(m).modelize is SingleGaussianLineModel.modelize
+                and type(m).gaussian is SingleGaussianLineModel.gaussian
+                and type(m).post_jump is LineModel.post_jump
+                and m.gibbs_parameter_index() == 0
+                and len(m.parameters()) == 3)
 
     def _write_checkpoint(self, name, iteration, accepted_count):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
         lib/run.py:790-797) and `<name>_chain.npy` (slots written so far)."""
-        np.save("%s_parameters.npy" % name, self.engine.get_params())
+        np.save("%s_parameters.npy" % name, self._host_chain.params if self._host_model
+                else self.engine.get_params())
         n_valid = (iteration - 1) // self.keep_one_in + 1
         np.save("%s_chain.npy" % name, self.chain[:n_valid])
         self.logger.info("checkpoint at iteration %d (%d accepted) -> %s_*.npy"
@@ -321,6 +348,8 @@ class Run:
     def simulate_clean(self, shape, parameters):
         """Cube of the raw lines (lib/run.py:597-621), built on the device."""
         self._check_shape(shape)
+        if self._host_model:
+            return self._host_chain.clean_cube(np.asarray(parameters, dtype=np.float64))
         self.engine.set_params(parameters)
         return self.engine.build_clean()
 
@@ -328,6 +357,9 @@ class Run:
         """Cube of the LSF- and FSF-convolved lines (lib/run.py:623-652), by the
         fused device forward model."""
         self._check_shape(shape)
+        if self._host_model:
+            return self.engine.convolve(
+                self._host_chain.clean_cube(np.asarray(parameters, dtype=np.float64)))
         self.engine.set_params(parameters)
         return self.engine.forward()
 
@@ -340,6 +372,11 @@ class Run:
         are the run's own.
         """
         self._check_shape((cube_depth, cube_height, cube_width))
+        if self._host_model:
+            one = np.zeros((cube_depth, cube_height, cube_width))
+            one[:, y, x] = np.asarray(self.model.modelize(self, np.arange(cube_depth, dtype=float),
+                                                          parameters), dtype=np.float64)
+            return self.engine.convolve(one), lsf_fft
         saved = self.engine.get_params()
         only = np.zeros_like(saved)
         only[..., 2] = 1.0

@@ -153,6 +153,20 @@ int d3d_window_stats(d3d_ctx *ctx, int y, int x, const double p_new[3],
  * the number of accepted MH proposals (lib/run.py:440). */
 int d3d_mh_sweeps(d3d_ctx *ctx, int n_sweeps, int first_sweep, int keep_one_in,
                   double *chain_out, double *dlog_out, int64_t *accepted);
+/* The same update for a line model evaluated on the HOST (a python LineModel
+ * plugin with its own modelize(), lib/line_models.py:17-61): n spaxels of one
+ * colour class (disjoint FSF windows; the caller guarantees it), per spaxel i
+ *   spaxels[i]          local index y*W+x
+ *   in3[i*3 + 0..2]     current Gibbs amplitude (1 if the model has none),
+ *                       out-of-bounds flag of the proposal (lib/run.py:379-384),
+ *                       log(u) of the acceptance test (lib/run.py:435)
+ *   lines[(i*2+0)*D..]  current line, unit amplitude (lib/run.py:472, 481-488)
+ *   lines[(i*2+1)*D..]  proposed line, unit amplitude
+ * The device applies the LSF, the window statistics, accept, the Gibbs draw of
+ * the amplitude when gibbs != 0 (bounds min_b[0]/max_b[0] of d3d_mh_config) and
+ * the residual update; out3[i*3 + 0..2] = {accepted, new amplitude, delta}. */
+int d3d_mh_colour_lines(d3d_ctx *ctx, int sweep, int n, const int *spaxels, const double *in3,
+                        const double *lines, int gibbs, double *out3);
 /* Last sweep's log acceptance ratios, (H,W). */
 int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
 

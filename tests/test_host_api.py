@@ -235,9 +235,3 @@ def test_run_rejects_bad_inputs_like_the_reference():
     with pytest.raises(ValueError, match="Initial params"): # lib/run.py:300-305
         d3d.Run(cube, inst, initial_parameters=np.zeros((3, 3, 3)))
 
-    class Custom(d3d.SingleGaussianLineModel):
-        def modelize(self, runner, x, parameters):
-            return np.zeros(len(x))
-
-    with pytest.raises(NotImplementedError):
-        d3d.Run(cube, inst, model=Custom)
