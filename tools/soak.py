@@ -1,0 +1,47 @@
+"""Long chain at BASELINE config 3 on one GPU: acceptance, reduced chi2 and the
+drift of the carried residual against a from-scratch one (lib/run.py:521-534).
+Writes a small report (profiles/<tag>_soak.txt when run through gpurun)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import WORKLOADS, build_taps, synthetic_inputs  # noqa: E402
+from deconv3d_amd import _lib  # noqa: E402
+
+n_sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+chunk = 250
+D, H, W, fs = WORKLOADS["c3_300x300x128"]
+fsf, lsf = build_taps(D, fs)
+eng = _lib.Engine((D, H, W), fsf.shape)
+eng.set_taps(fsf, lsf)
+data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 12345)
+eng.set_data(data, var)
+eng.set_params(init)
+eng.mh_config(min_b, max_b, [0., 0.5, 0.2], float(max_b[0] ** 2), seed=12345, refresh_every=1000)
+eng.residual(fetch=False)
+print("soak: %d sweeps of %dx%dx%d, jump amplitudes (0, 0.5, 0.2), refresh every 1000" % (n_sweeps, D, H, W))
+print("%8s %10s %12s %14s %10s" % ("sweep", "accept", "red.chi2", "drift(max|d|)", "M upd/s"))
+s = 1
+t_all = time.perf_counter()
+while s <= n_sweeps:
+    n = min(chunk, n_sweeps - s + 1)
+    t0 = time.perf_counter()
+    acc = eng.mh_sweeps(n, s)
+    dt = time.perf_counter() - t0
+    s += n
+    carried = eng.download_slot(_lib.SLOT_ERR)
+    _, total = eng.chi2_map()
+    saved = eng.get_params()
+    fresh = eng.residual()                      # from scratch (also what the refresh does)
+    drift = float(np.max(np.abs(carried - fresh)))
+    print("%8d %10.4f %12.4f %14.3e %10.2f" % (s - 1, acc / float(n * H * W), 2 * total / data.size,
+                                               drift, n * H * W / dt / 1e6), flush=True)
+p = eng.get_params()
+live = truth[..., 0] > 2.0
+print("median |c - c_true| over bright spaxels: %.3f channels" % np.median(np.abs(p[..., 1] - truth[..., 1])[live]))
+print("median |w - w_true| over bright spaxels: %.3f channels" % np.median(np.abs(p[..., 2] - truth[..., 2])[live]))
+print("total wall %.1f s" % (time.perf_counter() - t_all))
+eng.close()
