@@ -19,6 +19,8 @@ Fixtures
                        (tests/input/data14forAntoine.mat, Parametres_theoriques.mat)
                        re-laid out as (D,H,W) / (H,W,3): data, variance, 15x15
                        FSF, theoretical parameters (c already 0-based)
+  ref_galpak_pair.npz  the reference's saved convolved/deconvolved cube pair
+                       (tests/input/GalPaK_*_myrun100k_*.fits)
   oracle_*.npz         oracle outputs on the seeded parity cases (regression
                        pins + the vectors the GPU tests compare against)
 """
@@ -113,6 +115,19 @@ def ref_mat_fixture():
                         params=params)
 
 
+def ref_galpak_pair():
+    """The reference's own saved outputs of a 100k-iteration MUSE run
+    (tests/input/GalPaK_..._myrun100k_{convolved,deconvolved}_cube.fits, written
+    by Run.save_fits, lib/run.py:797-806): convolved = LSF x FSF of deconvolved
+    under the MUSE defaults (lib/instruments.py:95-107) to 0.4 % of the peak."""
+    from deconv3d_amd.cube import Cube
+    stem = os.path.join(REF, "tests/input/GalPaK_cube_1101_size4.08_flux1e-16_incl60_vmax199_"
+                             "disp80_seeing1.00_myrun100k_")
+    conv = Cube.from_fits(stem + "convolved_cube.fits").data
+    clean = Cube.from_fits(stem + "deconvolved_cube.fits").data
+    np.savez_compressed(os.path.join(HERE, "ref_galpak_pair.npz"), convolved=conv, clean=clean)
+
+
 def oracle_cases():
     for name in ("c1", "odd_depth", "asym"):
         case = make_case(name)
@@ -155,6 +170,7 @@ if __name__ == "__main__":
     ref_median_clip()
     ref_rtnorm()
     ref_mat_fixture()
+    ref_galpak_pair()
     oracle_cases()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

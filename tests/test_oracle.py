@@ -92,6 +92,28 @@ def test_reference_mat_fixture_known_answer():
     assert z2.std() > 1.5
 
 
+def test_reference_saved_cube_pair_known_answer():
+    """tests/input/GalPaK_*_myrun100k_{convolved,deconvolved}_cube.fits are the
+    reference's own Run.save_fits outputs (lib/run.py:797-806): the convolved
+    cube is LSF x FSF of the clean one under the MUSE defaults
+    (lib/instruments.py:95-107: Gaussian FSF fwhm 1.0"/0.2" px, Gaussian LSF fwhm
+    2.675 A/1.25 A px).  An older revision wrote them, so the agreement is 0.4 % of
+    the peak, not bit-level: a known answer for the
+    orientation, centring and normalisation of the whole convolution."""
+    g = gold("ref_galpak_pair.npz")
+    clean, conv = g["clean"], g["convolved"]
+    fsf = O.gaussian_fsf_image(1.0 / 0.2)
+    lsf = O.gaussian_lsf_vector(clean.shape[0], 2.675 / (2 * np.sqrt(2 * np.log(2))) / 1.25)
+    assert fsf.shape == (13, 13)
+    out = O.convolve_cube(clean, fsf, lsf)
+    assert np.abs(out - conv).max() < 5e-3 * conv.max()
+    # neither a transposed/shifted kernel nor a wrong seeing passes this bar
+    assert np.abs(O.convolve_cube(clean, O.gaussian_fsf_image(0.9 / 0.2), lsf) - conv).max() \
+        > 0.1 * conv.max()
+    assert np.abs(np.roll(out, 1, axis=0) - conv).max() > 0.05 * conv.max()
+    assert np.abs(np.roll(out, 1, axis=2) - conv).max() > 0.05 * conv.max()
+
+
 # ---- internal identities ---------------------------------------------------------
 
 def test_philox_known_answers():
