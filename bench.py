@@ -69,8 +69,11 @@ def synthetic_inputs(eng, D, H, W, fsf, seed, A0=10.0):
     eng.set_params(truth)
     clean = eng.forward()
     sigma = 0.05 * A0 * np.max(fsf)
-    data = clean + rng.normal(0., sigma, size=(D, H, W))
-    var = np.full((D, H, W), sigma ** 2)
+    # a genuine per-voxel variance cube (as MUSE's STAT extension is): the timed
+    # path is the general kernel that streams 1/var, not the uniform-variance
+    # variant (reported separately under "uniform_variance")
+    var = sigma ** 2 * rng.uniform(0.75, 1.25, size=(D, H, W))
+    data = clean + rng.normal(size=(D, H, W)) * np.sqrt(var)
     min_b = np.array([0., 0., 0.])
     max_b = np.array([np.amax(data) / np.amax(fsf), D - 1., float(D)])  # lib/line_models.py:79-90
     init = min_b + (max_b - min_b) * rng.random((H, W, 3))            # lib/run.py:310-314
@@ -312,12 +315,35 @@ def main():
                    if fs != 9 else "gaussian 9x9",
                    "lsf_taps": ntaps_lsf, "spaxels": n_spaxels,
                    "parallelism": "1 chain" if world == 1 else "ensemble of %d chains" % world,
-                   "variance": "full cube"},
+                   "variance": "per-voxel cube (heteroscedastic)"},
         "acceptance": round(accepted / float(args.steps * n_spaxels), 4),
         "roofline": roofline,
         "roofline_conv": roofline_conv,
         "roofline_conv_ref_layout": roofline_conv_ref_layout,
     }
+
+    if rank == 0:
+        # the reference's default variance (Run(variance=None): one constant,
+        # lib/run.py:171-178): the MH kernel does not read SLOT_IVAR at all
+        assert not eng.variance_is_uniform()
+        eng.set_data(data, None, var_scalar=float(np.mean(var)), mask=mask)
+        if eng.variance_is_uniform():
+            eng.set_params(init)
+            eng.residual(fetch=False)
+            eng.mh_sweeps(max(args.warmup, 1), 1)
+            eng.sync()
+            eng.timer_start()
+            eng.mh_sweeps(args.steps, 1 + max(args.warmup, 1))
+            u_ms = eng.timer_stop()
+            u_us = u_ms * 1e3 / launches
+            u_gbs = (bytes_per_sweep * 2 // 3) / ncol / (u_us * 1e-6) / 1e9
+            out["uniform_variance"] = {
+                "value": round(args.steps * n_spaxels / (u_ms * 1e-3), 1),
+                "unit": "spaxel-updates/s", "kernel": "k_mh_ws<..., uniform 1/var>",
+                "bytes_per_launch": bytes_per_sweep * 2 // 3 // ncol,
+                "avg_launch_us": round(u_us, 2), "achieved": round(u_gbs, 1),
+                "frac": round(u_gbs / HBM_PEAK_GBS, 4),
+                "note": "extra: reference default variance=None (one constant); not `value`"}
 
     if rank == 0 and not args.no_cpu:
         cores = len(os.sched_getaffinity(0))

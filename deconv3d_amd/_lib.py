@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdeconv3d_hip.so")
+# DECONV3D_HIP_LIB: another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("DECONV3D_HIP_LIB") or os.path.join(_HERE, "csrc", "libdeconv3d_hip.so")
 
 # every symbol include/deconv3d_hip.h declares (tests check the export list)
 SYMBOLS = [
@@ -26,7 +27,8 @@ SYMBOLS = [
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
     "d3d_convolve_slots", "d3d_stage_upload", "d3d_stage_convolve", "d3d_stage_download",
     "d3d_mh_config", "d3d_window_stats",
-    "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_colour_count",
+    "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform",
+    "d3d_colour_count",
     "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
 
@@ -94,6 +96,7 @@ def load():
     lib.d3d_mh_sweeps.argtypes = [ctx_p, C.c_int, C.c_int, C.c_int, dbl_p,
                                   dbl_p, C.POINTER(C.c_int64)]
     lib.d3d_get_dlog.argtypes = [ctx_p, dbl_p]
+    lib.d3d_variance_is_uniform.argtypes = [ctx_p, C.POINTER(C.c_int)]
     lib.d3d_mh_colour_lines.argtypes = [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_int), dbl_p,
                                         dbl_p, C.c_int, dbl_p]
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
@@ -332,6 +335,11 @@ class Engine(object):
         out = np.empty(self.shape[1:], dtype=np.float64)
         _check(self._lib.d3d_get_dlog(self._ctx, _dp(out)))
         return out
+
+    def variance_is_uniform(self):
+        flag = C.c_int(0)
+        _check(self._lib.d3d_variance_is_uniform(self._ctx, C.byref(flag)))
+        return bool(flag.value)
 
     def colour_count(self, colour):
         n = C.c_int(0)

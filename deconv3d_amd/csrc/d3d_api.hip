@@ -93,6 +93,13 @@ struct d3d_ctx {
 
     int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
     int mh_defer = 1;             // deferred residual write-back (k_mh_defer)
+#ifdef D3D_EXPERIMENTS
+    unsigned long long *stampbuf = nullptr;  // D3D_MH_STAMP=1: [launch][workgroup][8]
+    size_t stamp_launches = 0, stamp_next = 0, stamp_stride = 0;
+#endif
+    bool ivar_is_uniform = false; // SLOT_IVAR holds one constant (k_mh_ws<.., true> skips reading it)
+    double ivar_uniform = 0.0;
+    bool uniform_fast_path = true;  // D3D_UNIFORM_IVAR=0 turns the variant off
     double *gbuf[2] = {nullptr, nullptr};  // pending update coefficients [slots][Dp]
     int gpar = 0;                 // gbuf[gpar] holds the pending updates
     int pend_cy = -1, pend_cx = -1;  // colour class of the pending updates (-1: none)
@@ -477,6 +484,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.npos = c->fh * c->fw;
     P.err = c->slot[D3D_SLOT_ERR];
     P.ivar = c->slot[D3D_SLOT_IVAR];
+    P.ivar_uniform = c->ivar_uniform;
     P.params = c->params;
     P.prev = c->prev;
     P.fsf = c->fsf;
@@ -510,6 +518,9 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.probe_sp = 0;
     P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
     P.probe_out = c->scal;
+#ifdef D3D_EXPERIMENTS
+    P.stamp = nullptr;
+#endif
 }
 
 template <int NT, int MAXIT>
@@ -550,24 +561,22 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <int NS, int NPW>
+template <bool UV>
 int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    const size_t lds =
-        d3d::mh_ws_lds_doubles(NS, NPW, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, NPW>), dim3(grid), dim3(NS + 64 * NPW), lds,
+    constexpr int NS = 256;
+    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV>), dim3(grid), dim3(NS + 64), lds,
                        c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    // wave-specialised kernel: 256 streaming threads + one prepare wavefront per
-    // 64 channels (D <= 256)
-    if (c->mh_defer == 1 && c->D <= 256 && c->HL <= 256) {
-        const int npw = (c->D + 63) / 64;
-        if (npw == 1) return launch_mh_ws<256, 1>(c, P, grid, sweep);
-        if (npw == 2) return launch_mh_ws<256, 2>(c, P, grid, sweep);
-        return launch_mh_ws<256, 4>(c, P, grid, sweep);
+    // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
+    // tail, so D <= 256) + one prepare wavefront
+    if (c->mh_defer == 1 && c->Dp <= 256) {
+        if (c->ivar_is_uniform && c->uniform_fast_path) return launch_mh_ws<true>(c, P, grid, sweep);
+        return launch_mh_ws<false>(c, P, grid, sweep);
     }
     switch (c->mh_nt) {
         case 128: return launch_mh_defer_nt<128>(c, P, grid, sweep);
@@ -626,6 +635,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     c->mh_maxit = maxit;
     // 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain
     if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
+    if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
 }
 
 int build_colour_lists(d3d_ctx *c) {
@@ -818,6 +828,9 @@ int d3d_ctx_destroy(d3d_ctx *c) {
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+#ifdef D3D_EXPERIMENTS
+    if (c->stampbuf) (void)hipFree(c->stampbuf);
+#endif
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -949,10 +962,29 @@ int d3d_set_data(d3d_ctx *c, const double *data, const double *var, double var_s
     const size_t n = (size_t)c->D * c->HW;
     // mask: user mask AND no NaN anywhere in the spectrum (lib/run.py:153-162)
     for (long s = 0; s < c->HW; ++s) c->h_mask[s] = mask ? (mask[s] == 1) : 1;
+    bool any_nan = false;
     for (int z = 0; z < c->D; ++z) {
         const double *pl = data + (size_t)z * c->HW;
         for (long s = 0; s < c->HW; ++s)
-            if (pl[s] != pl[s]) c->h_mask[s] = 0;
+            if (pl[s] != pl[s]) {
+                c->h_mask[s] = 0;
+                any_nan = true;
+            }
+    }
+    // one constant 1/variance everywhere (scalar variance, or a cube of equal
+    // values as the reference builds when none is given, lib/run.py:171-178) and
+    // no NaN voxel (those get 1/var = 0): the MH kernel need not read SLOT_IVAR.
+    {
+        const double v0 = var ? var[0] : var_scalar;
+        bool uni = !any_nan && v0 == v0;
+        if (uni && var)
+            for (size_t i = 1; i < n; ++i)
+                if (var[i] != v0) {
+                    uni = false;
+                    break;
+                }
+        c->ivar_is_uniform = uni;
+        c->ivar_uniform = uni ? 1.0 / (v0 == 0.0 ? 1e12 : v0) : 0.0;
     }
     HIP_TRY(hipMemcpyAsync(c->mask, c->h_mask.data(), (size_t)c->HW, hipMemcpyHostToDevice,
                            c->stream));
@@ -1022,6 +1054,7 @@ int d3d_convolve_slots(d3d_ctx *c, int src, int dst) {
     HIP_TRY(hipSetDevice(c->device));
     if (src == D3D_SLOT_ERR)
         if (int rc = flush_pending(c)) return rc;
+    if (dst == D3D_SLOT_IVAR) c->ivar_is_uniform = false;
     const double *in = c->slot[src];
     if (c->ntaps > 0) {
         // FSF and LSF act on different axes and commute: when possible the LSF is
@@ -1045,6 +1078,7 @@ int d3d_upload_slot(d3d_ctx *c, int slot, const double *cube) {
         c->err_valid = true;
         c->pend_cy = c->pend_cx = -1;
     }
+    if (slot == D3D_SLOT_IVAR) c->ivar_is_uniform = false;
     return D3D_OK;
 }
 
@@ -1241,6 +1275,11 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
             if (c->mh_defer && !c->tiled) {
                 // real + virtual positions: the windows of this launch tile the cube
                 const int n_all = c->colour_off[col + 1] - c->colour_off[col];
+#ifdef D3D_EXPERIMENTS
+                if (c->stampbuf && c->stamp_next < c->stamp_launches &&
+                    (size_t)n_all * 8 <= c->stamp_stride)
+                    P.stamp = c->stampbuf + (c->stamp_next++) * c->stamp_stride;
+#endif
                 int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
                 if (rc) return rc;
                 c->gpar ^= 1;  // this launch's updates are now the pending ones
@@ -1280,6 +1319,45 @@ int d3d_get_dlog(d3d_ctx *c, double *out_hw) {
     HIP_TRY(hipMemcpyAsync(out_hw, c->dlog, (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+#ifdef D3D_EXPERIMENTS
+// Phase stamps of the next `launches` colour launches of d3d_mh_sweeps
+// (tools/mh_phases.py).  d3d_x_stamps_read copies launch `i`'s n*8 stamps out.
+int d3d_x_stamps_arm(d3d_ctx *c, int launches) {
+    NEED(c && launches > 0, D3D_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->stampbuf) HIP_TRY(hipFree(c->stampbuf));
+    NEED(c->have_data, D3D_ERR_STATE, "data not set");
+    size_t most = 0;
+    for (size_t k = 0; k + 1 < c->colour_off.size(); ++k)
+        most = std::max(most, (size_t)(c->colour_off[k + 1] - c->colour_off[k]));
+    c->stamp_stride = most * 8;
+    c->stamp_launches = (size_t)launches;
+    c->stamp_next = 0;
+    const size_t bytes = c->stamp_launches * c->stamp_stride * sizeof(unsigned long long);
+    HIP_TRY(hipMalloc((void **)&c->stampbuf, bytes));
+    HIP_TRY(hipMemset(c->stampbuf, 0, bytes));
+    return D3D_OK;
+}
+
+int d3d_x_stamps_read(d3d_ctx *c, int launch, int n, unsigned long long *out) {
+    NEED(c && out && c->stampbuf && launch >= 0 && (size_t)launch < c->stamp_launches && n > 0,
+         D3D_ERR_INVALID, "bad argument");
+    if ((size_t)n * 8 > c->stamp_stride) n = (int)(c->stamp_stride / 8);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->stampbuf + (size_t)launch * c->stamp_stride,
+                      (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return D3D_OK;
+}
+#endif
+
+int d3d_variance_is_uniform(d3d_ctx *c, int *out) {
+    NEED(c && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_data, D3D_ERR_STATE, "data not set");
+    *out = (c->ivar_is_uniform && c->uniform_fast_path) ? 1 : 0;
     return D3D_OK;
 }
 

@@ -1163,6 +1163,7 @@ struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
     double *err;
     const double *ivar;
+    double ivar_uniform;  // the constant 1/variance when the cube is uniform (k_mh_ws<.., true>)
     double *params;
     double *prev;  // [H*W*3] parameters before the last update of each spaxel, or NULL
     const double *fsf;
@@ -1204,7 +1205,22 @@ struct MHArgs {
     int probe_sp;
     double probe_p[3];
     double *probe_out;
+#ifdef D3D_EXPERIMENTS
+    // k_mh_ws phase stamps (100 MHz wall clock), 8 slots per workgroup: 0 entry,
+    // 1 setup done, 2 window streamed, 3 prepare wavefront done, 4 update written
+    // (tools/mh_phases.py)
+    unsigned long long *stamp;
+#endif
 };
+
+#ifdef D3D_EXPERIMENTS
+#define D3D_MH_STAMP(k, who)                                                          \
+    do {                                                                              \
+        if (P.stamp && threadIdx.x == (who)) P.stamp[(long)blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define D3D_MH_STAMP(k, who)
+#endif
 
 __host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos) {
     const int G = NT / HL;
@@ -1320,8 +1336,9 @@ __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const 
 
 // From the per-channel window sums to the new state.  ch = this thread's
 // channel (threads with ch >= D carry zeros), `first` = index of the first of
-// the nw wavefronts that call this (they are consecutive).  Contains one block
-// barrier.  Returns false in probe mode.
+// the nw wavefronts that call this (they are consecutive).  Contains two block
+// barriers that every thread of the workgroup must reach.  Returns false in
+// probe mode and to non-callers.
 __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, const MHProposal &q,
                                           int sp, uint32_t sweep, int ch, int G, double EO,
                                           double EN, int first, int nw, bool caller,
@@ -1358,72 +1375,79 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
         }
     }
     __syncthreads();
-    if (!caller) return false;
-    double tot[7];
+    // One wavefront takes the decision (every lane the same numbers) and leaves
+    // {accepted, amplitude} in the spare slots behind the wave sums: the fp64
+    // special functions of the truncated normal would otherwise be issued by
+    // every wavefront of every resident workgroup at the same moment.
+    double *verdict = S.sum + 8 * nw;
+    if (caller && (int)(threadIdx.x >> 6) == first) {
+        double tot[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        double t = 0.0;
-        for (int wv = 0; wv < nw; ++wv) t += S.sum[wv * 8 + k];
-        tot[k] = t;
-    }
-    const double ar_old = 0.5 * tot[2];
-    const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
-
-    if (P.probe) {
-        if (ch == 0) {
-            P.probe_out[0] = ar_old;
-            P.probe_out[1] = ar_old - delta;
-            P.probe_out[2] = delta;
-            P.probe_out[3] = tot[3];
-            P.probe_out[4] = tot[4];
+        for (int k = 0; k < 7; ++k) {
+            double t = 0.0;
+            for (int wv = 0; wv < nw; ++wv) t += S.sum[wv * 8 + k];
+            tot[k] = t;
         }
+        const double ar_old = 0.5 * tot[2];
+        const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
+        const bool lead = (threadIdx.x & 63) == 0;
+        if (P.probe) {
+            if (lead) {
+                P.probe_out[0] = ar_old;
+                P.probe_out[1] = ar_old - delta;
+                P.probe_out[2] = delta;
+                P.probe_out[3] = tot[3];
+                P.probe_out[4] = tot[4];
+            }
+        } else {
+            // ---- MH accept (lib/run.py:435-445) --------------------------------
+            const bool accept = (q.log_u < delta) && !q.oob;
+            // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
+            const double s_ee = accept ? tot[5] : tot[3];
+            const double s_eu = accept ? tot[6] : tot[4];
+            // ---- Gibbs draw of the amplitude (lib/run.py:456-499) --------------
+            double r;
+            if (P.ext_lines && !P.ext_gibbs) {
+                r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
+            } else {
+                const double ro = P.ra / (1.0 + P.ra * s_ee);
+                const double mu = ro * s_eu;
+                uint32_t blk = BLK_GIBBS;
+                r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep,
+                                     &blk);
+            }
+            if (lead) {
+                verdict[0] = accept ? 1.0 : 0.0;
+                verdict[1] = r;
+                if (P.ext_lines) {
+                    double *o3 = P.ext_out + (long)blockIdx.x * 3;
+                    o3[0] = accept ? 1.0 : 0.0;
+                    o3[1] = r;
+                    o3[2] = delta;
+                } else {
+                    if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
+                        P.prev[(long)sp * 3 + 0] = q.a_old;
+                        P.prev[(long)sp * 3 + 1] = q.c_old;
+                        P.prev[(long)sp * 3 + 2] = q.w_old;
+                    }
+                    P.params[(long)sp * 3 + 0] = r;
+                    P.params[(long)sp * 3 + 1] = accept ? q.pn[1] : q.c_old;
+                    P.params[(long)sp * 3 + 2] = accept ? q.pn[2] : q.w_old;
+                }
+                P.dlog[sp] = delta;
+                if (accept) atomicAdd(P.accepted, 1ULL);
+            }
+        }
+    }
+    __syncthreads();
+    if (!caller || P.probe) {
         *Gz_out = 0.0;
         return false;
     }
-
-    // ---- MH accept (lib/run.py:435-445) ------------------------------------
-    const bool accept = (q.log_u < delta) && !q.oob;
-    const double c_end = accept ? q.pn[1] : q.c_old;
-    const double w_end = accept ? q.pn[2] : q.w_old;
-    const double Eend = accept ? EN : EO;
-    // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
-    const double s_ee = accept ? tot[5] : tot[3];
-    const double s_eu = accept ? tot[6] : tot[4];
-
-    // ---- Gibbs draw of the amplitude (lib/run.py:456-499) ------------------
-    double r;
-    if (P.ext_lines && !P.ext_gibbs) {
-        r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
-    } else {
-        const double ro = P.ra / (1.0 + P.ra * s_ee);
-        const double mu = ro * s_eu;
-        uint32_t blk = BLK_GIBBS;
-        r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep, &blk);
-    }
-
+    const bool accept = verdict[0] != 0.0;
+    const double r = verdict[1];
     // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
-    *Gz_out = (ch < D) ? residual_coeff(q.a_old, EO, r, Eend) : 0.0;
-    if (ch == 0) {
-        if (P.ext_lines) {
-            double *o3 = P.ext_out + (long)blockIdx.x * 3;
-            o3[0] = accept ? 1.0 : 0.0;
-            o3[1] = r;
-            o3[2] = delta;
-            P.dlog[sp] = delta;
-            if (accept) atomicAdd(P.accepted, 1ULL);
-            return true;
-        }
-        if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
-            P.prev[(long)sp * 3 + 0] = q.a_old;
-            P.prev[(long)sp * 3 + 1] = q.c_old;
-            P.prev[(long)sp * 3 + 2] = q.w_old;
-        }
-        P.params[(long)sp * 3 + 0] = r;
-        P.params[(long)sp * 3 + 1] = c_end;
-        P.params[(long)sp * 3 + 2] = w_end;
-        P.dlog[sp] = delta;
-        if (accept) atomicAdd(P.accepted, 1ULL);
-    }
+    *Gz_out = (ch < D) ? residual_coeff(q.a_old, EO, r, accept ? EN : EO) : 0.0;
     return true;
 }
 
@@ -1686,29 +1710,40 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
 }
 
 // Wave-specialised deferred kernel: NS streaming threads run the window pass
-// while NPW extra wavefronts (thread <-> channel) compute everything of the
-// decision that does not depend on the window -- proposal (Philox, tan), both
-// unit lines (exp) and their LSF convolution -- so that only the short tail
-// (sums -> accept -> truncated normal) follows the pass.  Each prepare
-// wavefront builds the zero-extended unit lines in its own LDS region
-// (wave-private: no block barrier while the others stream).  Same arithmetic,
-// same summation order, bit-identical results as k_mh_defer.
-__host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int NPW, int HL, int Dp, int N,
-                                                    int npos) {
-    return mh_lds_doubles(NS, HL, Dp, N, npos) + (size_t)NPW * 2 * N;
+// while ONE extra wavefront computes everything of the decision that does not
+// depend on the window -- proposal (Philox, tan), both unit lines (exp) and
+// their LSF convolution, channel by channel into LDS -- so that only the short
+// tail (sums -> accept -> truncated normal; streaming thread t <-> channel t)
+// follows the pass.  The prepare wavefront works in its own LDS region (no
+// block barrier while the others stream) and is done long before the stream
+// (tools/mh_phases.py).  320 threads and ~29 KB of LDS per workgroup at D = 128:
+// four workgroups per CU, so that every window of a colour launch is resident
+// at once.  Same arithmetic, same summation order, bit-identical results as
+// k_mh_defer.
+__host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int N, int npos) {
+    return mh_lds_doubles(NS, HL, Dp, N, npos) + (size_t)Dp + 16;
 }
 
-template <int NS, int NPW>
-__global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t sweep) {
+// UV = true: the 1/variance cube is one constant (the reference's default when
+// no variance is given, lib/run.py:171-178, and no NaN voxel): the streaming
+// threads take it from P.ivar_uniform instead of reading SLOT_IVAR -- 16 instead
+// of 24 bytes per window voxel, same arithmetic, bit-identical results.
+template <int NS, bool UV>
+__global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
-    constexpr int NT = NS + 64 * NPW;
+    constexpr int NT = NS + 64;
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp, N = P.N;
     const int G = NS / HL;
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     const MHShared S = mh_carve(smem, NS, HL, Dp, N, P.npos);
-    double *priv = S.sum + 8 * (NS / 64) + 8;
+    // S.gO / S.gN: the prepare wavefront's zero-extended unit lines; S.G and sEN:
+    // the LSF-convolved lines per channel; sq: the proposal
+    double *sEN = S.sum + 8 * (NS / 64) + 8;
+    MHProposal *sq = reinterpret_cast<MHProposal *>(sEN + Dp);
+    static_assert(sizeof(MHProposal) <= 16 * sizeof(double), "proposal does not fit its LDS slot");
 
+    D3D_MH_STAMP(0, 0);
     const int4 ent = P.spx[blockIdx.x];
     const int y = ent.x, x = ent.y;  // may lie outside the cube when virtual
     const bool real = ent.z != 0;
@@ -1753,15 +1788,16 @@ __global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t swee
         S.gp[i] = gv;
     }
     __syncthreads();
+    D3D_MH_STAMP(1, 0);
 
     const bool streamer = tid < NS;
-    MHProposal q = {};
-    double EO = 0.0, EN = 0.0;
-    int ch = 0;
     if (streamer) {
         const int g = tid / HL, zl = tid - g * HL;
         if (g < G) {
             double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+            // the padding channel of an odd depth carries 1/var = 0
+            const double2 vu = make_double2(P.ivar_uniform,
+                                            (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
 #pragma unroll 4
             for (int p = g; p < P.npos; p += G) {
                 const int vox = S.pos[3 * p + 0];
@@ -1769,7 +1805,8 @@ __global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t swee
                 const int tap = S.pos[3 * p + 1];
                 const long idx = (long)vox * Dp + 2 * zl;
                 double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
-                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                double2 v = vu;
+                if (!UV) v = *reinterpret_cast<const double2 *>(P.ivar + idx);
                 if (tap >= 0) {
                     const double fp = S.fsf[tap];
                     const double2 gz = *reinterpret_cast<const double2 *>(
@@ -1792,23 +1829,38 @@ __global__ __launch_bounds__(NS + 64 * NPW) void k_mh_ws(MHArgs P, uint32_t swee
             }
         }
     } else if (real) {
-        const int pw = (tid - NS) >> 6, lane = tid & 63;
-        ch = tid - NS;
-        q = mh_propose(P, sp, sweep);
-        double *gO = priv + (size_t)pw * 2 * N;
-        double *gN = gO + N;
+        const int lane = tid - NS;
+        const MHProposal q = mh_propose(P, sp, sweep);
         for (int j = lane; j < N; j += 64) {
-            gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
-            gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+            S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
+            S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
         }
         __builtin_amdgcn_wave_barrier();  // wave-private region: LDS is in order per wave
-        mh_lsf(P, gO, gN, ch, &EO, &EN);
+        for (int ch = lane; ch < Dp; ch += 64) {
+            double EO, EN;
+            mh_lsf(P, S.gO, S.gN, ch, &EO, &EN);
+            S.G[ch] = EO;
+            sEN[ch] = EN;
+        }
+        if (lane == 0) *sq = q;
+        D3D_MH_STAMP(3, NS);  // prepare wavefront done (long before the stream)
     }
+    D3D_MH_STAMP(2, 0);
     if (!real) return;
-    __syncthreads();  // group partial sums are in S.red
+    __syncthreads();  // group partial sums are in S.red, the lines in S.G / sEN
+    MHProposal q = {};
+    double EO = 0.0, EN = 0.0;
+    if (streamer) {
+        q = *sq;
+        if (tid < Dp) {
+            EO = S.G[tid];
+            EN = sEN[tid];
+        }
+    }
     double Gt;
-    if (!mh_finish(P, S, q, sp, sweep, ch, G, EO, EN, NS / 64, NPW, !streamer, &Gt)) return;
-    if (ch < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + ch] = Gt;
+    if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt)) return;
+    if (tid < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + tid] = Gt;
+    D3D_MH_STAMP(4, 0);
 }
 
 // Replay of updates made by ANOTHER tile (multi-GPU spatial tiling): one

@@ -169,6 +169,12 @@ int d3d_mh_colour_lines(d3d_ctx *ctx, int sweep, int n, const int *spaxels, cons
                         const double *lines, int gibbs, double *out3);
 /* Last sweep's log acceptance ratios, (H,W). */
 int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
+/* *out = 1 when d3d_set_data found one constant variance and no NaN voxel -- the
+ * reference's default when Run gets variance=None (lib/run.py:171-178 builds a
+ * constant cube from median_clip) -- so that d3d_mh_sweeps streams the residual
+ * only (16 instead of 24 bytes per window voxel; results are bit-identical to
+ * the general kernel).  Environment D3D_UNIFORM_IVAR=0 turns the variant off. */
+int d3d_variance_is_uniform(d3d_ctx *ctx, int *out);
 
 /* ---- spatial tiling (one chain over several GPUs) --------- */
 /* The reference has no counterpart (single process).  A tile ctx holds a

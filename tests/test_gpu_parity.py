@@ -169,6 +169,66 @@ def test_write_back_schemes_are_bit_identical(monkeypatch, name):
             np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["c1", "odd_depth", "big_fsf"])
+@pytest.mark.parametrize("how", ["scalar", "constant cube"])
+def test_uniform_variance_variant_is_bit_identical(monkeypatch, name, how):
+    """One constant variance (the reference's default, lib/run.py:171-178): the
+    MH kernel takes 1/var from a register instead of SLOT_IVAR.  Same
+    arithmetic as the general kernel (D3D_UNIFORM_IVAR=0) -> bit-identical
+    chains, residuals and delta maps; and it matches the oracle."""
+    case = make_case(name)
+    shape = (case["D"], case["H"], case["W"])
+    v0 = float(np.median(case["var"]))
+    var_cube = np.full(shape, v0)
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("D3D_UNIFORM_IVAR", knob)
+        from deconv3d_amd import _lib
+        with _lib.Engine(shape, case["fsf"].shape) as eng:
+            eng.set_taps(case["fsf"], case["lsf"])
+            if how == "scalar":
+                eng.set_data(case["data"], None, var_scalar=v0, mask=case["mask"])
+            else:
+                eng.set_data(case["data"], var_cube, mask=case["mask"])
+            assert eng.variance_is_uniform() == (knob == "1")
+            eng.set_params(case["init"])
+            eng.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=31, refresh_every=0)
+            eng.mh_sweeps(2, 1)
+            outs.append((eng.get_params(), eng.download_slot(2), eng.get_dlog()))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+    st = O.MHState(case["data"], var_cube, case["mask"], case["fsf"], case["lsf"], case["init"],
+                   case["min_b"], case["max_b"], jump_amplitude=0.1, gibbs_apriori_variance=50.0,
+                   seed=31)
+    for s in (1, 2):
+        O.mh_sweep(st, s)
+    live = case["mask"] == 1
+    np.testing.assert_allclose(outs[0][0][live], st.params[live], rtol=1e-9, atol=1e-9)
+    assert_cube_close(outs[0][1], st.err, "carried residual (uniform variance)")
+
+
+def test_uniform_variance_detection():
+    """NaN voxels (1/var = 0 there), a non-constant cube, or a later upload into
+    SLOT_IVAR all select the general kernel."""
+    from deconv3d_amd import _lib
+    case = make_case("tiny")
+    shape = (case["D"], case["H"], case["W"])
+    with _lib.Engine(shape, case["fsf"].shape) as eng:
+        eng.set_taps(case["fsf"], case["lsf"])
+        eng.set_data(case["data"], None, var_scalar=2.0)
+        assert eng.variance_is_uniform()
+        eng.set_data(case["data"], case["var"])
+        assert not eng.variance_is_uniform()
+        holed = case["data"].copy()
+        holed[1, 0, 2] = np.nan
+        eng.set_data(holed, None, var_scalar=2.0)
+        assert not eng.variance_is_uniform()
+        eng.set_data(case["data"], np.full(shape, 0.0))       # var == 0 -> 1e12 everywhere
+        assert eng.variance_is_uniform()
+        eng.upload_slot(_lib.SLOT_IVAR, 1.0 / case["var"])
+        assert not eng.variance_is_uniform()
+
+
 def test_residual_refresh_keeps_chain_consistent():
     """lib/run.py:521-534: the periodic from-scratch residual only removes
     ~1e-14 creep."""
