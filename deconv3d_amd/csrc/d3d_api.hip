@@ -100,8 +100,19 @@ struct d3d_ctx {
     bool ivar_is_uniform = false; // SLOT_IVAR holds one constant (k_mh_ws<.., true> skips reading it)
     double ivar_uniform = 0.0;
     bool uniform_fast_path = true;  // D3D_UNIFORM_IVAR=0 turns the variant off
-    double *gbuf[2] = {nullptr, nullptr};  // pending update coefficients [slots][Dp]
-    int gpar = 0;                 // gbuf[gpar] holds the pending updates
+    double *gbuf[3] = {nullptr, nullptr, nullptr};  // update coefficients [slots][Dp]
+    int gpend = 0;                // gbuf[gpend] holds the pending updates
+    // dataflow kernel (k_mh_flow): one launch per sweep
+    int mh_flow = 0;              // D3D_MH_FLOW=1: one launch per sweep (k_mh_flow; measured
+                                  // slower than one k_mh_ws launch per colour: DESIGN.md)
+    int flow_K = 0, flow_LY = 0, flow_LX = 0, flow_items = 0, flow_grid = 0;
+    int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
+    int4 *flow_ent = nullptr;     // [items] {y, x, real, colour ordinal}
+    int4 *flow_col = nullptr;     // [K] {first ticket, cy, cx, -}
+    int *flow_lat = nullptr;      // [K][LY*LX]
+    unsigned *flow_state = nullptr;  // one block, zeroed per launch: ctl[4] | cnt[K] | done[items]
+    unsigned *flow_err = nullptr;    // sticky error word of k_mh_flow
+    size_t flow_state_bytes = 0, flow_cap_items = 0, flow_cap_K = 0;
     int pend_cy = -1, pend_cx = -1;  // colour class of the pending updates (-1: none)
     int slots_x = 0, slots = 0;
     int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
@@ -504,8 +515,8 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.gx0 = c->gx0;
     P.Wg = c->Wg;
     P.mask = c->mask;
-    P.Gprev = c->gbuf[c->gpar];
-    P.Gcur = c->gbuf[c->gpar ^ 1];
+    P.Gprev = c->gbuf[c->gpend];
+    P.Gcur = c->gbuf[(c->gpend + 1) % 3];
     P.prev_cy = c->pend_cy;
     P.prev_cx = c->pend_cx;
     P.slots_x = c->slots_x;
@@ -568,6 +579,48 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV>), dim3(grid), dim3(NS + 64), lds,
                        c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One sweep in one launch (k_mh_flow).  P carries the pending colour of the
+// previous sweep; afterwards the last active colour of this one is pending.
+template <bool UV>
+int launch_mh_flow_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHFlow &F, uint32_t sweep) {
+    constexpr int NS = 256;
+    size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    lds += 16;  // the ticket
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_flow<NS, UV>), dim3((unsigned)c->flow_items),
+                       dim3(NS + 64), lds, c->stream, P, F, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
+    HIP_TRY(hipMemsetAsync(c->flow_state, 0, c->flow_state_bytes, c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    d3d::MHFlow F;
+    F.ent = c->flow_ent;
+    F.col = c->flow_col;
+    F.lat = c->flow_lat;
+    F.ctl = c->flow_state;
+    F.cnt = c->flow_state + 4;
+    F.done = c->flow_state + 4 + c->flow_cap_K;
+    F.err = c->flow_err;
+    for (int b = 0; b < 3; ++b) F.gbuf[b] = c->gbuf[b];
+    F.K = c->flow_K;
+    F.LY = c->flow_LY;
+    F.LX = c->flow_LX;
+    F.pb = c->gpend;
+    F.items = c->flow_items;
+    F.epoch = 1;
+    const int rc = (c->ivar_is_uniform && c->uniform_fast_path)
+                       ? launch_mh_flow_t<true>(c, P, F, sweep)
+                       : launch_mh_flow_t<false>(c, P, F, sweep);
+    if (rc) return rc;
+    c->gpend = (c->gpend + c->flow_K) % 3;
+    c->pend_cy = c->flow_last_cy;
+    c->pend_cx = c->flow_last_cx;
     return 0;
 }
 
@@ -636,6 +689,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     // 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain
     if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
+    if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
 }
 
 int build_colour_lists(d3d_ctx *c) {
@@ -674,6 +728,44 @@ int build_colour_lists(d3d_ctx *c) {
         }
     c->colour_off[ncol] = (int)list.size();
     if (list.size() > c->spx_cap) return fail(D3D_ERR_HIP, "internal: colour list overflow");
+    // tables of the dataflow kernel: active colours in order, their ticket
+    // ranges, and per colour the map lattice point -> index in its list
+    c->flow_K = 0;
+    c->flow_items = 0;
+    c->flow_last_cy = c->flow_last_cx = -1;
+    if (!c->tiled) {
+        std::vector<int4> ents, cols;
+        std::vector<int> lat((size_t)ncol * c->flow_LY * c->flow_LX, -1);
+        for (int col = 0; col < ncol; ++col) {
+            if (c->colour_real[col] <= 0) continue;
+            const int cy = col / c->fw, cx = col % c->fw;  // == local residues (not tiled)
+            const int n_all = c->colour_off[col + 1] - c->colour_off[col];
+            const int k = (int)cols.size();
+            cols.push_back(make_int4((int)ents.size(), cy, cx, 0));
+            for (int i = 0; i < n_all; ++i) {
+                const int4 e = list[(size_t)c->colour_off[col] + i];
+                const int iy = (e.x - cy) / c->fh + 1, ix = (e.y - cx) / c->fw + 1;
+                if (iy < 0 || iy >= c->flow_LY || ix < 0 || ix >= c->flow_LX)
+                    return fail(D3D_ERR_HIP, "internal: lattice index out of range");
+                lat[((size_t)k * c->flow_LY + iy) * c->flow_LX + ix] = i;
+                ents.push_back(make_int4(e.x, e.y, e.z, k));
+            }
+            c->flow_last_cy = cy;
+            c->flow_last_cx = cx;
+        }
+        c->flow_K = (int)cols.size();
+        c->flow_items = (int)ents.size();
+        if (c->flow_K > 0) {
+            HIP_TRY(hipMemcpyAsync(c->flow_ent, ents.data(), ents.size() * sizeof(int4),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->flow_col, cols.data(), cols.size() * sizeof(int4),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->flow_lat, lat.data(),
+                                   (size_t)c->flow_K * c->flow_LY * c->flow_LX * sizeof(int),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
+        }
+    }
     if (!list.empty())
         HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int4),
                                hipMemcpyHostToDevice, c->stream));
@@ -803,9 +895,26 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->prev, (size_t)c->HW * 3 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->recbuf, (size_t)c->HW * 8 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->idxbuf, (size_t)c->HW * sizeof(int)));
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 3; ++b) {
         CTX_TRY(hipMalloc(&c->gbuf[b], (size_t)c->slots * c->Dp * sizeof(double)));
         CTX_TRY(hipMemsetAsync(c->gbuf[b], 0, (size_t)c->slots * c->Dp * sizeof(double), c->stream));
+    }
+    {
+        const size_t ncol = (size_t)fh * fw;
+        c->flow_LY = H / fh + 3;
+        c->flow_LX = W / fw + 3;
+        c->flow_cap_K = ncol;
+        c->flow_cap_items = c->spx_cap;
+        CTX_TRY(hipMalloc(&c->flow_ent, c->spx_cap * sizeof(int4)));
+        CTX_TRY(hipMalloc(&c->flow_col, ncol * sizeof(int4)));
+        CTX_TRY(hipMalloc(&c->flow_lat, ncol * c->flow_LY * c->flow_LX * sizeof(int)));
+        c->flow_state_bytes = ((4 + ncol + c->spx_cap) * sizeof(unsigned) + 15) / 16 * 16;
+        CTX_TRY(hipMalloc(&c->flow_state, c->flow_state_bytes));
+        CTX_TRY(hipMalloc(&c->flow_err, 16));
+        CTX_TRY(hipMemsetAsync(c->flow_err, 0, 16, c->stream));
+        int cus = 0;
+        CTX_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        c->flow_grid = 4 * (cus > 0 ? cus : 256);
     }
     CTX_TRY(hipMemsetAsync(c->dlog, 0, (size_t)c->HW * sizeof(double), c->stream));
     CTX_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
@@ -824,7 +933,8 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
-                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1],
+                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2],
+                    c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1265,8 +1375,15 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
     const int ncol = c->fh * c->fw;
+    // k_mh_flow addresses SLOT_ERR through a raw buffer (32-bit byte offsets)
+    const bool flow = c->mh_flow && c->mh_defer == 1 && !c->tiled && c->Dp <= 256 &&
+                      c->flow_K > 0 && c->cube_elems * sizeof(double) < (size_t(1) << 31);
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
-        for (int col = 0; col < ncol; ++col) {
+        if (flow) {
+            int rc = launch_mh_flow(c, (uint32_t)s);
+            if (rc) return rc;
+        }
+        for (int col = 0; col < ncol && !flow; ++col) {
             const int n_real = c->colour_real[col];
             if (n_real <= 0) continue;
             d3d::MHArgs P;
@@ -1282,7 +1399,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
 #endif
                 int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
                 if (rc) return rc;
-                c->gpar ^= 1;  // this launch's updates are now the pending ones
+                c->gpend = (c->gpend + 1) % 3;  // this launch's updates are now the pending ones
                 c->pend_cy = ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
                 c->pend_cx = ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw;
             } else {
@@ -1308,9 +1425,14 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
         }
     }
     unsigned long long acc = 0;
+    unsigned flow_err = 0;
     HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
+    if (flow)
+        HIP_TRY(hipMemcpyAsync(&flow_err, c->flow_err, sizeof flow_err, hipMemcpyDeviceToHost,
+                               c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (accepted) *accepted = (int64_t)acc;
+    NEED(!flow_err, D3D_ERR_HIP, "k_mh_flow: a dependency wait timed out; the chain state is invalid");
     return D3D_OK;
 }
 

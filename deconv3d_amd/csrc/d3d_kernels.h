@@ -1214,12 +1214,12 @@ struct MHArgs {
 };
 
 #ifdef D3D_EXPERIMENTS
-#define D3D_MH_STAMP(k, who)                                                          \
+#define D3D_MH_STAMP(at, k, who)                                                      \
     do {                                                                              \
-        if (P.stamp && threadIdx.x == (who)) P.stamp[(long)blockIdx.x * 8 + (k)] = wall_clock64(); \
+        if (P.stamp && threadIdx.x == (who)) P.stamp[(long)(at) * 8 + (k)] = wall_clock64(); \
     } while (0)
 #else
-#define D3D_MH_STAMP(k, who)
+#define D3D_MH_STAMP(at, k, who)
 #endif
 
 __host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos) {
@@ -1728,50 +1728,46 @@ __host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int 
 // no variance is given, lib/run.py:171-178, and no NaN voxel): the streaming
 // threads take it from P.ivar_uniform instead of reading SLOT_IVAR -- 16 instead
 // of 24 bytes per window voxel, same arithmetic, bit-identical results.
-template <int NS, bool UV>
-__global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
-    extern __shared__ double smem[];
-    constexpr int NT = NS + 64;
-    const int tid = threadIdx.x;
-    const int HL = P.HL, Dp = P.Dp, N = P.N;
-    const int G = NS / HL;
+//
+// The workgroup's work on one window, in three steps shared by k_mh_ws (one
+// launch per colour) and k_mh_flow (one launch per sweep):
+//   mh_ws_table  position table + taps into LDS (geometry and mask only)
+//   mh_ws_gp     the <= 4 pending G rows of the previous colour into LDS
+//   mh_ws_run    window pass + prepare wavefront + decision + G row out
+struct MHWsItem {
+    int y, x, real;
+    int prev_cy, prev_cx;  // colour class of the pending updates, -1 = none
+    int psy0, psy1, psx0, psx1;  // the <= 2 x 2 pending spaxels that cover this window
+                                 // (scalars: a dynamically indexed array lands in scratch)
+    const double *Gprev;
+    double *Gcur;
+};
+
+__device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, MHWsItem &I,
+                                            int NT) {
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
-    const MHShared S = mh_carve(smem, NS, HL, Dp, N, P.npos);
-    // S.gO / S.gN: the prepare wavefront's zero-extended unit lines; S.G and sEN:
-    // the LSF-convolved lines per channel; sq: the proposal
-    double *sEN = S.sum + 8 * (NS / 64) + 8;
-    MHProposal *sq = reinterpret_cast<MHProposal *>(sEN + Dp);
-    static_assert(sizeof(MHProposal) <= 16 * sizeof(double), "proposal does not fit its LDS slot");
-
-    D3D_MH_STAMP(0, 0);
-    const int4 ent = P.spx[blockIdx.x];
-    const int y = ent.x, x = ent.y;  // may lie outside the cube when virtual
-    const bool real = ent.z != 0;
-    const int sp = y * P.W + x;
-    if (!real && P.prev_cy < 0) return;
-
-    int psy[2], psx[2];
-    if (P.prev_cy >= 0) {
-        psy[0] = covering_coord(max(y - fhh, 0), P.prev_cy, P.fh, fhh, P.H);
-        psy[1] = covering_coord(min(y + fhh, P.H - 1), P.prev_cy, P.fh, fhh, P.H);
-        psx[0] = covering_coord(max(x - fhw, 0), P.prev_cx, P.fw, fhw, P.W);
-        psx[1] = covering_coord(min(x + fhw, P.W - 1), P.prev_cx, P.fw, fhw, P.W);
+    const int y = I.y, x = I.x;
+    if (I.prev_cy >= 0) {
+        I.psy0 = covering_coord(max(y - fhh, 0), I.prev_cy, P.fh, fhh, P.H);
+        I.psy1 = covering_coord(min(y + fhh, P.H - 1), I.prev_cy, P.fh, fhh, P.H);
+        I.psx0 = covering_coord(max(x - fhw, 0), I.prev_cx, P.fw, fhw, P.W);
+        I.psx1 = covering_coord(min(x + fhw, P.W - 1), I.prev_cx, P.fw, fhw, P.W);
     } else {
-        psy[0] = psy[1] = psx[0] = psx[1] = -1;
+        I.psy0 = I.psy1 = I.psx0 = I.psx1 = -1;
     }
-    for (int p = tid; p < P.npos; p += NT) {
+    for (int p = threadIdx.x; p < P.npos; p += NT) {
         S.fsf[p] = P.fsf[p];
         const int dy = p / P.fw, dx = p - dy * P.fw;
         const int yy = y + dy - fhh, xx = x + dx - fhw;
         int vox = -1, tap = -1, sel = 0;
         if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
             vox = yy * P.W + xx;
-            if (P.prev_cy >= 0) {
-                const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
-                const int sx = covering_coord(xx, P.prev_cx, P.fw, fhw, P.W);
+            if (I.prev_cy >= 0) {
+                const int sy = covering_coord(yy, I.prev_cy, P.fh, fhh, P.H);
+                const int sx = covering_coord(xx, I.prev_cx, P.fw, fhw, P.W);
                 if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx]) {
                     tap = (yy - sy + fhh) * P.fw + (xx - sx + fhw);
-                    sel = (sy == psy[0] ? 0 : 2) + (sx == psx[0] ? 0 : 1);
+                    sel = (sy == I.psy0 ? 0 : 2) + (sx == I.psx0 ? 0 : 1);
                 }
             }
         }
@@ -1779,17 +1775,50 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         S.pos[3 * p + 1] = tap;
         S.pos[3 * p + 2] = sel;
     }
-    for (int i = tid; i < 4 * Dp; i += NT) {
+}
+
+// COH (k_mh_flow): the rows were written in THIS launch by workgroups of any
+// XCD -- agent-scope (sc1) loads, never served from a stale L1 line.
+template <bool COH>
+__device__ __forceinline__ void mh_ws_gp(const MHArgs &P, const MHShared &S, const MHWsItem &I,
+                                         int NT) {
+    const int Dp = P.Dp;
+    for (int i = threadIdx.x; i < 4 * Dp; i += NT) {
         const int q = i / Dp, z = i - q * Dp;
-        const int sy = psy[q >> 1], sx = psx[q & 1];
+        const int sy = (q >> 1) ? I.psy1 : I.psy0, sx = (q & 1) ? I.psx1 : I.psx0;
         double gv = 0.0;
-        if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx])
-            gv = P.Gprev[((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z];
+        if (sy >= 0 && sx >= 0 && P.mask[sy * P.W + sx]) {
+            const double *src = I.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
+            if (COH)
+                gv = __longlong_as_double((long long)__hip_atomic_load(
+                    reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
+                    __HIP_MEMORY_SCOPE_AGENT));
+            else
+                gv = *src;
+        }
         S.gp[i] = gv;
     }
-    __syncthreads();
-    D3D_MH_STAMP(1, 0);
+}
 
+// Needs S.pos / S.fsf / S.gp complete (block barrier before the call).  Contains
+// block barriers only when I.real (uniform over the workgroup).
+// COH (k_mh_flow): the residual and the G rows are handed from workgroup to
+// workgroup inside the launch: write-through (sc1) stores and sc1 loads for
+// every such byte, so that neither a release nor an acquire fence is needed
+// (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
+template <int NS, bool UV, bool COH>
+__device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
+                                          uint32_t sweep, long stamp_at) {
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp, N = P.N;
+    const int G = NS / HL;
+    // S.gO / S.gN: the prepare wavefront's zero-extended unit lines; S.G and sEN:
+    // the LSF-convolved lines per channel; sq: the proposal
+    double *sEN = S.sum + 8 * (NS / 64) + 8;
+    MHProposal *sq = reinterpret_cast<MHProposal *>(sEN + Dp);
+    static_assert(sizeof(MHProposal) <= 16 * sizeof(double), "proposal does not fit its LDS slot");
+    const bool real = I.real != 0;
+    const int sp = I.y * P.W + I.x;
     const bool streamer = tid < NS;
     if (streamer) {
         const int g = tid / HL, zl = tid - g * HL;
@@ -1798,25 +1827,57 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
             // the padding channel of an odd depth carries 1/var = 0
             const double2 vu = make_double2(P.ivar_uniform,
                                             (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
+            // raw buffer over SLOT_ERR (the launcher checks that it is < 2 GiB); aux 16 = sc1
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            union { double2 d; v4u i; } cv;
+            const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                P.err, 0, COH ? (int)((long)P.H * P.W * Dp * 8) : 0, 0x00020000);
+            // U window positions per round: all their loads are issued before the
+            // first is consumed (a lone straggler workgroup is latency-bound
+            // otherwise).  Positions outside the cube load voxel 0 and are skipped;
+            // the sums still run in increasing p.
+            constexpr int U = 1;
 #pragma unroll 4
-            for (int p = g; p < P.npos; p += G) {
-                const int vox = S.pos[3 * p + 0];
-                if (vox < 0) continue;
-                const int tap = S.pos[3 * p + 1];
-                const long idx = (long)vox * Dp + 2 * zl;
-                double2 e = *reinterpret_cast<const double2 *>(P.err + idx);
-                double2 v = vu;
-                if (!UV) v = *reinterpret_cast<const double2 *>(P.ivar + idx);
-                if (tap >= 0) {
-                    const double fp = S.fsf[tap];
-                    const double2 gz = *reinterpret_cast<const double2 *>(
-                        S.gp + S.pos[3 * p + 2] * Dp + 2 * zl);
-                    e.x = fma(fp, gz.x, e.x);
-                    e.y = fma(fp, gz.y, e.y);
-                    *reinterpret_cast<double2 *>(P.err + idx) = e;
+            for (int p0 = g; p0 < P.npos; p0 += U * G) {
+                int vox[U];
+                double2 e[U], v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + u * G;
+                    vox[u] = (p < P.npos) ? S.pos[3 * p + 0] : -1;
+                    const long idx = (long)max(vox[u], 0) * Dp + 2 * zl;
+                    if (COH) {
+                        cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
+                        e[u] = cv.d;
+                    } else {
+                        e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
+                    }
+                    v[u] = vu;
+                    if (!UV) v[u] = *reinterpret_cast<const double2 *>(P.ivar + idx);
                 }
-                const double f = S.fsf[p];
-                D3D_ACCUM(e, v, f);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (vox[u] < 0) continue;
+                    const int p = p0 + u * G;
+                    const int tap = S.pos[3 * p + 1];
+                    const long idx = (long)vox[u] * Dp + 2 * zl;
+                    if (tap >= 0) {
+                        const double fp = S.fsf[tap];
+                        const double2 gz = *reinterpret_cast<const double2 *>(
+                            S.gp + S.pos[3 * p + 2] * Dp + 2 * zl);
+                        e[u].x = fma(fp, gz.x, e[u].x);
+                        e[u].y = fma(fp, gz.y, e[u].y);
+                        if (COH) {
+                            cv.d = e[u];
+                            __builtin_amdgcn_raw_buffer_store_b128(cv.i, err_rsrc, (int)(idx * 8), 0,
+                                                                   16);
+                        } else {
+                            *reinterpret_cast<double2 *>(P.err + idx) = e[u];
+                        }
+                    }
+                    const double f = S.fsf[p];
+                    D3D_ACCUM(e[u], v[u], f);
+                }
             }
             if (real) {
                 double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
@@ -1843,9 +1904,9 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
             sEN[ch] = EN;
         }
         if (lane == 0) *sq = q;
-        D3D_MH_STAMP(3, NS);  // prepare wavefront done (long before the stream)
+        D3D_MH_STAMP(stamp_at, 3, NS);  // prepare wavefront done (long before the stream)
     }
-    D3D_MH_STAMP(2, 0);
+    D3D_MH_STAMP(stamp_at, 2, 0);
     if (!real) return;
     __syncthreads();  // group partial sums are in S.red, the lines in S.G / sEN
     MHProposal q = {};
@@ -1859,8 +1920,187 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     }
     double Gt;
     if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt)) return;
-    if (tid < Dp) P.Gcur[((long)(y / P.fh) * P.slots_x + x / P.fw) * Dp + tid] = Gt;
-    D3D_MH_STAMP(4, 0);
+    if (tid < Dp) {
+        double *dst = I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * Dp + tid;
+        if (COH)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst),
+                               (unsigned long long)__double_as_longlong(Gt), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        else
+            *dst = Gt;
+    }
+    D3D_MH_STAMP(stamp_at, 4, 0);
+}
+
+template <int NS, bool UV>
+__global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    constexpr int NT = NS + 64;
+    const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos);
+    D3D_MH_STAMP(blockIdx.x, 0, 0);
+    const int4 ent = P.spx[blockIdx.x];
+    MHWsItem I;
+    I.y = ent.x;  // may lie outside the cube when virtual
+    I.x = ent.y;
+    I.real = ent.z;
+    I.prev_cy = P.prev_cy;
+    I.prev_cx = P.prev_cx;
+    I.Gprev = P.Gprev;
+    I.Gcur = P.Gcur;
+    if (!I.real && I.prev_cy < 0) return;  // nothing pending, nothing to do
+    mh_ws_table(P, S, I, NT);
+    mh_ws_gp<false>(P, S, I, NT);
+    __syncthreads();
+    D3D_MH_STAMP(blockIdx.x, 1, 0);
+    mh_ws_run<NS, UV, false>(P, S, I, sweep, blockIdx.x);
+}
+
+// ---- one launch per sweep: dataflow over the colour classes ----------------
+//
+// OPT-IN (D3D_MH_FLOW=1).  Measured on MI355X at 300x300x128 / 11x11: 54.9 us
+// per colour against 48.4 us for one k_mh_ws launch per colour (uniform
+// variance: 49.0 vs 39.1) -- the chain colour k -> k+1 is serial per window, so
+// every microsecond of hand-off latency (ticket, flag poll, write-through drain)
+// is on the critical path, and only the ~240 workgroup slots a colour leaves
+// free can be staged ahead.  Kept because it is bit-identical to the default and
+// exercises the in-launch hand-off at full size (tests/test_gpu_full_size.py).
+//
+// k_mh_ws pays for the kernel boundary after every colour: all workgroups set
+// up at the same moment, the slowest window of the colour holds up the next
+// launch, and the L2 write-back at the end of the kernel is exposed
+// (tools/mh_phases.py: ~13 of 48 us per colour at 300x300x128).  But a window
+// of colour k only depends on the <= 4 windows of colour k-1 that intersect it
+// (they wrote its residual voxels and hold the G rows it must apply).
+// k_mh_flow runs a whole sweep in one launch, one workgroup per window: each
+// draws a ticket (items in colour order), waits for the completion flags of
+// exactly those predecessors, and publishes its own.  Tickets are handed out in
+// dependency order and a workgroup only waits for LOWER tickets, which are
+// held by workgroups that are already running -- the lowest unfinished ticket
+// can always proceed.  Every spin has a wall-clock timeout that raises
+// *F.err and lets the grid drain.
+//
+// The XCDs' L2s are not coherent with each other and a CU's L1 is never
+// refreshed by another CU's stores.  Release/acquire fences per item (L2
+// write-back, L1 invalidate: ~7 us each with four workgroups per CU) sit on the
+// colour-to-colour critical path and cost more than the kernel boundary they
+// replace (measured: 76 vs 48 us per colour).  Instead every byte that is handed
+// over inside the launch -- the residual and the G rows -- is stored
+// write-through (sc1) and loaded sc1; the storing waves drain (vmcnt(0)) before
+// one lane raises the flag.
+// G rows cycle through three buffers (colour k writes buffer (pb+k+1) mod 3 and
+// reads (pb+k) mod 3); an item of colour k also waits until colour k-2 is
+// complete, so that no reader of the buffer it overwrites is still running.
+struct MHFlow {
+    const int4 *ent;    // [tickets] {y, x, real, ordinal of the colour among the active ones}
+    const int4 *col;    // [K] {first ticket of the colour, cy, cx, -}
+    const int *lat;     // [K][LY*LX] lattice point -> index in the colour's list, -1 = none
+    unsigned *done;     // [tickets] epoch in which the item was finished
+    unsigned *cnt;      // [K] finished items of each colour (this launch)
+    unsigned *ctl;      // [0] next ticket
+    unsigned *err;      // sticky: a dependency wait timed out
+    double *gbuf[3];
+    int K, LY, LX, pb, items;
+    unsigned epoch;
+};
+
+__device__ __forceinline__ int covering_lattice(int q, int c, int per, int hw) {
+    int m = (q - c) % per;
+    if (m < 0) m += per;
+    int s = q - m;
+    if (q - s > hw) s += per;
+    return s;
+}
+
+__device__ __forceinline__ bool flow_wait(const unsigned *addr, unsigned want, bool at_least,
+                                          unsigned *err) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at_least ? (v >= want) : (v == want)) return true;
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000ULL) {  // 2 s at 100 MHz: give up, let the grid drain
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+    }
+}
+
+template <int NS, bool UV>
+__global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_t sweep) {
+    extern __shared__ double smem[];
+    constexpr int NT = NS + 64;
+    const int tid = threadIdx.x;
+    const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos);
+    int *s_item = reinterpret_cast<int *>(smem + mh_ws_lds_doubles(NS, P.HL, P.Dp, P.N, P.npos));
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    // The ticket, not blockIdx, orders the items: a workgroup that has drawn one is
+    // running, whatever order the dispatcher admits workgroups in.
+    if (tid == 0)
+        *s_item = (int)__hip_atomic_fetch_add(F.ctl, 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // uniform over the workgroup: keep it (and all that follows from it) scalar
+    const int item = __builtin_amdgcn_readfirstlane(*s_item);
+    if (item >= F.items) return;
+    const int4 ent = F.ent[item];  // {y, x, real, colour ordinal}
+    const int k = ent.w;
+    const int4 col = F.col[k];     // {first ticket, cy, cx, -}
+    MHWsItem I;
+    I.y = ent.x;
+    I.x = ent.y;
+    I.real = ent.z;
+    int prev_off = 0, prev2_off = 0;
+    if (k > 0) {
+        const int4 pc = F.col[k - 1];
+        I.prev_cy = pc.y;
+        I.prev_cx = pc.z;
+        prev_off = pc.x;
+        if (k > 1) prev2_off = F.col[k - 2].x;
+    } else {
+        I.prev_cy = P.prev_cy;
+        I.prev_cx = P.prev_cx;
+    }
+    I.Gprev = F.gbuf[(F.pb + k) % 3];
+    I.Gcur = F.gbuf[(F.pb + k + 1) % 3];
+    const bool idle = !I.real && I.prev_cy < 0;  // nothing pending, nothing to do
+    bool ok = true;
+    if (!idle) mh_ws_table(P, S, I, NT);
+    if (k > 0 && tid < 5) {
+        // lanes 0..3: the predecessors (lattice points of colour k-1 whose windows
+        // intersect this one inside the cube); lane 4: colour k-2 complete
+        if (tid < 4) {
+            const int wy = (tid >> 1) ? min(I.y + fhh, P.H - 1) : max(I.y - fhh, 0);
+            const int wx = (tid & 1) ? min(I.x + fhw, P.W - 1) : max(I.x - fhw, 0);
+            const int sy = covering_lattice(wy, I.prev_cy, P.fh, fhh);
+            const int sx = covering_lattice(wx, I.prev_cx, P.fw, fhw);
+            const int iy = (sy - I.prev_cy) / P.fh + 1, ix = (sx - I.prev_cx) / P.fw + 1;
+            int li = -1;
+            if (iy >= 0 && iy < F.LY && ix >= 0 && ix < F.LX)
+                li = F.lat[((long)(k - 1) * F.LY + iy) * F.LX + ix];
+            if (li >= 0) ok = flow_wait(F.done + prev_off + li, F.epoch, false, F.err);
+        } else if (k > 1) {
+            ok = flow_wait(F.cnt + (k - 2), (unsigned)(prev_off - prev2_off), true, F.err);
+        }
+    }
+    // every handed-off byte is stored and loaded sc1 (mh_ws_gp<true>,
+    // mh_ws_run<.., true>): no acquire; only keep the loads below the polls
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // a timed-out wait skips the item (*F.err is set: the host reports it)
+    if (__syncthreads_or(!ok)) return;
+    if (!idle) {
+        mh_ws_gp<true>(P, S, I, NT);
+        __syncthreads();
+        mh_ws_run<NS, UV, true>(P, S, I, sweep, item);
+    }
+    // every storing wave drains its write-through stores, then one lane raises
+    // the flag (cdna_hip_programming.md, Guideline 16 R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_store(F.done + item, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(F.cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Replay of updates made by ANOTHER tile (multi-GPU spatial tiling): one

@@ -96,6 +96,37 @@ def test_chain_reproducible_and_residual_consistent(problem):
     np.testing.assert_allclose(total, ref.sum(), rtol=1e-10)
 
 
+@pytest.mark.parametrize("uniform", [False, True])
+def test_sweep_dataflow_kernel_equals_per_colour_launches(monkeypatch, problem, uniform):
+    """k_mh_flow (one launch per sweep; windows wait for the flags of the <= 4
+    windows of the previous colour they intersect, hand-off through agent-scope
+    release/acquire across the XCDs) against k_mh_ws (a kernel boundary after
+    every colour): 270 000 updates, chains, residuals and delta maps
+    bit-identical.  A stale line anywhere in a window
+    would show up here."""
+    var = problem["var"] if uniform else problem["var"] * (
+        0.75 + 0.5 * np.random.default_rng(5).random(problem["var"].shape))
+    outs = []
+    for env in ({"D3D_MH_FLOW": "1"}, {"D3D_MH_FLOW": "0"}):
+        for k in ("D3D_MH_FLOW", "D3D_MH_DEFER"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with _lib.Engine((D, H, W), problem["fsf"].shape) as eng:
+            eng.set_taps(problem["fsf"], problem["lsf"])
+            eng.set_data(problem["data"], var)
+            assert eng.variance_is_uniform() == uniform
+            eng.set_params(problem["init"])
+            eng.mh_config(problem["min_b"], problem["max_b"], 0.1,
+                          float(problem["max_b"][0] ** 2), seed=4242, refresh_every=0)
+            acc = eng.mh_sweeps(3, 1)
+            outs.append((np.int64(acc), eng.get_params(), eng.get_dlog(),
+                         eng.download_slot(_lib.SLOT_ERR)))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_window_probe_matches_oracle_on_full_cube(problem):
     eng, rng = problem["eng"], problem["rng"]
     eng.set_params(problem["init"])
