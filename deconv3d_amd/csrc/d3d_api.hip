@@ -2,6 +2,7 @@
 // Host-side context, device memory, launch geometry.  gfx950 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -123,6 +124,8 @@ struct d3d_ctx {
     int *idxbuf = nullptr;           // [HW] staging of spaxel lists
     double *extbuf = nullptr;        // external-lines staging: [cap][6 + 2D] doubles
     size_t ext_cap = 0;              // spaxels per d3d_mh_colour_lines call it can hold
+    bool fsf_sep = false;         // fsf == u v^T to rounding (k_spatial_sep); D3D_SPATIAL_SEP=0 disables
+    double *sep_uv = nullptr;     // [fh + fw] on the device
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
@@ -314,8 +317,26 @@ int launch_march_stamped(d3d_ctx *c, d3d::SpatialArgs A, const double *in, doubl
 
 #endif  // D3D_EXPERIMENTS
 
+template <int NT, int FS>
+int launch_sep(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    constexpr int TX = (FS >= 9 ? 3 : 4);
+    const int S = NT / c->HL;
+    const int HY = c->march_hy;
+    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
+    const unsigned grid = (unsigned)((items + S - 1) / S);
+    if ((c->HL % 64) == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep<NT, FS, TX, true>), dim3(grid),
+                           dim3(NT), 0, c->stream, A, in, out, HY);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep<NT, FS, TX, false>), dim3(grid),
+                           dim3(NT), 0, c->stream, A, in, out, HY);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    if (!FUSE && A.sep_uv) return launch_sep<NT, FS>(c, A, in, out);
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool symx = c->march_mode >= 2 && c->fsf_symx;
@@ -404,6 +425,7 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.fsf = c->fsf;
     A.data = data;
     A.lsf_dense = nullptr;
+    A.sep_uv = (c->fsf_sep && !fuse_lsf) ? c->sep_uv : nullptr;
     A.xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
     A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
     A.dbg = nullptr;
@@ -878,6 +900,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->params, (size_t)c->HW * 3 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->mask, (size_t)c->HW));
     CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->sep_uv, (size_t)(fh + fw) * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_shift, (size_t)c->N * sizeof(int)));
     CTX_TRY(hipMalloc(&c->lsf_weight, (size_t)c->N * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_dense, (2 * d3d::LSF_RL + 1) * sizeof(double)));
@@ -934,7 +957,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2],
-                    c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err,
+                    c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -996,6 +1019,32 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
                 c->fsf_symy = false;
                 break;
             }
+    // outer product?  u = centre column / centre tap, v = centre row
+    {
+        const int cy = (c->fh - 1) / 2, cx = (c->fw - 1) / 2;
+        const double cc = fsf[cy * c->fw + cx];
+        double amax = 0.0;
+        for (int i = 0; i < c->fh * c->fw; ++i) amax = std::max(amax, std::fabs(fsf[i]));
+        std::vector<double> uv((size_t)c->fh + c->fw);
+        bool sep = cc != 0.0 && amax > 0.0;
+        if (sep) {
+            for (int k = 0; k < c->fh; ++k) uv[k] = fsf[k * c->fw + cx] / cc;
+            for (int m = 0; m < c->fw; ++m) uv[c->fh + m] = fsf[cy * c->fw + m];
+            for (int k = 0; k < c->fh && sep; ++k)
+                for (int m = 0; m < c->fw; ++m)
+                    if (!(std::fabs(fsf[k * c->fw + m] - uv[k] * uv[c->fh + m]) <=
+                          8.0 * 2.220446049250313e-16 * amax)) {
+                        sep = false;
+                        break;
+                    }
+        }
+        if (const char *e = getenv("D3D_SPATIAL_SEP")) sep = sep && atoi(e) != 0;
+        c->fsf_sep = sep;
+        if (sep)
+            HIP_TRY(hipMemcpyAsync(c->sep_uv, uv.data(), uv.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // uv goes out of scope
+    }
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
     if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
     if (const char *e = getenv("D3D_MARCH_ONE")) c->march_one = atoi(e);

@@ -251,6 +251,7 @@ struct SpatialArgs {
     // wl[j], j = 0..2*LSF_RL, so that out[k] = sum_j wl[j] * v[(k + j - LSF_RL) mod Dp]
     // (closed form of convolve_1d for power-of-two depths, lib/convolution.py:89-120)
     const double *lsf_dense;
+    const double *sep_uv;  // k_spatial_sep: u[fh] | v[fw] with fsf == u v^T (or NULL)
     int xcd_remap;  // XCD-aware block order in the march kernel
     int alt_dir;    // alternate the march direction of vertically adjacent strips
     int stagger;    // start delay (x ~2000 cycles) of every other workgroup, 0 = none
@@ -629,6 +630,129 @@ __global__ __launch_bounds__(NT, (NT <= 512 ? 2 : 4)) void k_spatial_march(
             d[6] = t_begin;
             d[7] = t_end;
         }
+    }
+}
+
+// Column march for an FSF that is an outer product, fsf[k][m] == u[k] * v[m] to
+// rounding -- every Gaussian FSF with pa = 0 (the reference's MUSE default,
+// lib/instruments.py:95-107, lib/spread_functions.py:94-131) is.  Same strips,
+// ring and block order as k_spatial_march, but an input row is first reduced
+// along x, X[t] = sum_m v[m] * row[t + FS - 1 - m], and X then feeds the FS ring
+// slots with u[k]: 2*FS FMAs per output instead of FS*FS -- at FS = 11 the pass
+// is bound by HBM, not by FP64.  The result differs from the 2-D sum by rounding
+// only (the host checks |fsf - u v^T| <= 8 eps max|fsf| before choosing this).
+template <int NT, int FS, int TX, bool UNI>
+__global__ __launch_bounds__(NT, 2) void k_spatial_sep(SpatialArgs A, const double *__restrict__ in,
+                                                       double *__restrict__ out, int HY) {
+    constexpr int FHH = (FS - 1) / 2;
+    constexpr int NR = TX + FS - 1;  // inputs per row
+    __shared__ double s_uv[2 * FS];  // u (tap rows, y) | v (tap columns, x)
+    for (int i = threadIdx.x; i < 2 * FS; i += NT) s_uv[i] = A.sep_uv[i];
+    __syncthreads();
+
+    const int S = NT / A.HL;
+    int s = threadIdx.x / A.HL;
+    const int zl = threadIdx.x - s * A.HL;
+    if constexpr (UNI) s = __builtin_amdgcn_readfirstlane(s);
+    const int nxs = (A.W + TX - 1) / TX;
+    const int nys = (A.H + HY - 1) / HY;
+    int blk = blockIdx.x;  // XCD-aware block order, as in k_spatial_march
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+    }
+    const long item = (long)blk * S + s;
+    if (s >= S || item >= (long)nxs * nys) return;
+    const int ys = (int)(item / nxs);
+    const int x0 = (int)(item - (long)ys * nxs) * TX;
+    const int y0 = ys * HY;
+    const int yend = min(y0 + HY, A.H);
+    const long rowstride = (long)A.W * A.Dp;
+    const bool xin = (x0 - FHH >= 0) && (x0 + TX - 1 + FHH < A.W);
+
+    double2 ring[FS][TX];
+#pragma unroll
+    for (int k = 0; k < FS; ++k)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
+
+    // the march is unrolled by FS and ring slot k of phase ph lives in physical
+    // register (ph + k) % FS: the slot of an output row never moves
+    const int nsteps = (yend - y0) + 2 * FHH;
+    int r = y0 - FHH;
+    for (int sbase = 0; sbase < nsteps; sbase += FS)
+#pragma unroll
+    for (int ph = 0; ph < FS; ++ph) {
+        if (sbase + ph >= nsteps) continue;
+        if (r >= 0 && r < A.H) {
+            const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
+            double2 row[NR];
+            if (xin) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    row[i] = *reinterpret_cast<const double2 *>(base + (long)i * A.Dp);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int xx = x0 - FHH + i;
+                    row[i] = (xx >= 0 && xx < A.W)
+                                 ? *reinterpret_cast<const double2 *>(base + (long)i * A.Dp)
+                                 : make_double2(0.0, 0.0);
+                }
+            }
+            // taps re-read from LDS every step (opaque zero: no 2*FS pinned registers)
+            int opq = 0;
+            asm volatile("" : "+v"(opq));
+            const double *uv = s_uv + opq;
+            double2 X[TX];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const double v0 = uv[FS];
+                X[t].x = v0 * row[t + FS - 1].x;
+                X[t].y = v0 * row[t + FS - 1].y;
+            }
+#pragma unroll
+            for (int m = 1; m < FS; ++m) {
+                const double vm = uv[FS + m];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    X[t].x = fma(vm, row[t + FS - 1 - m].x, X[t].x);
+                    X[t].y = fma(vm, row[t + FS - 1 - m].y, X[t].y);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FS; ++k) {
+                const int oy = r - FHH + k;
+                if (oy >= y0 && oy < yend) {
+                    const double uk = uv[k];
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        ring[(ph + k) % FS][t].x = fma(uk, X[t].x, ring[(ph + k) % FS][t].x);
+                        ring[(ph + k) % FS][t].y = fma(uk, X[t].y, ring[(ph + k) % FS][t].y);
+                    }
+                }
+            }
+        }
+        const int oy0 = r - FHH;  // slot 0 has received its last tap row
+        if (oy0 >= y0 && oy0 < yend) {
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const int xo = x0 + t;
+                if (xo < A.W) {
+                    const long o = (long)oy0 * rowstride + (long)xo * A.Dp + 2 * zl;
+                    double2 v = ring[ph % FS][t];
+                    if (A.data) {
+                        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+                        v.x = d.x - v.x;
+                        v.y = d.y - v.y;
+                    }
+                    *reinterpret_cast<double2 *>(out + o) = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[ph % FS][t] = make_double2(0.0, 0.0);
+        r += 1;
     }
 }
 

@@ -67,6 +67,41 @@ def test_convolve_arbitrary_cube(name):
     assert_cube_close(out, O.convolve_cube(cube, case["fsf"], case["lsf"]), "convolve")
 
 
+@pytest.mark.parametrize("kind", ["gaussian", "elliptical", "outer product of two ramps"])
+@pytest.mark.parametrize("shape", [(128, 40, 37), (30, 21, 50)])
+def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
+    """An FSF that is u v^T to rounding (every Gaussian with pa = 0) runs the
+    spatial pass as 2*FS taps (k_spatial_sep).  Against the oracle's 2-D sum and
+    against the device's own 2-D kernel (D3D_SPATIAL_SEP=0): rounding only."""
+    from deconv3d_amd import _lib
+    from deconv3d_amd.spread_functions import gaussian_image
+    rng = np.random.default_rng(3)
+    if kind == "gaussian":
+        fsf = gaussian_image(4.0)
+    elif kind == "elliptical":
+        fsf = gaussian_image(3.2, pa=0., ba=0.6)
+    else:
+        fsf = np.outer(np.linspace(0.2, 1.4, 7), np.linspace(2.0, 0.5, 7))
+        fsf /= fsf.sum()
+    assert fsf.shape[0] == fsf.shape[1]
+    D, H, W = shape
+    lsf = O.gaussian_lsf_vector(D, 0.8)
+    cube = rng.normal(size=shape)
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("D3D_SPATIAL_SEP", knob)
+        with _lib.Engine(shape, fsf.shape) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.upload_slot(_lib.SLOT_TMP0, cube)
+            eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+            outs.append(eng.download_slot(_lib.SLOT_SIM))
+    ref = O.convolve_cube(cube, fsf, lsf)
+    assert_cube_close(outs[0], ref, "separable pass vs oracle")
+    assert_cube_close(outs[1], ref, "2-D pass vs oracle")
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-13 * np.max(np.abs(ref))
+    assert not np.array_equal(outs[0], outs[1])      # two different summation orders did run
+
+
 def test_reference_saved_cube_pair_on_device():
     """The reference's own saved pair (tests/golden/ref_galpak_pair.npz, see
     tests/test_oracle.py): the HIP convolution of its clean cube under the MUSE
