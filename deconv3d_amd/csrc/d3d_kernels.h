@@ -1867,8 +1867,7 @@ struct MHWsItem {
     double *Gcur;
 };
 
-__device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, MHWsItem &I,
-                                            int NT) {
+__device__ __forceinline__ void mh_ws_preds(const MHArgs &P, MHWsItem &I) {
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     const int y = I.y, x = I.x;
     if (I.prev_cy >= 0) {
@@ -1879,6 +1878,13 @@ __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, 
     } else {
         I.psy0 = I.psy1 = I.psx0 = I.psx1 = -1;
     }
+}
+
+// needs mh_ws_preds
+__device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, const MHWsItem &I,
+                                            int NT) {
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    const int y = I.y, x = I.x;
     for (int p = threadIdx.x; p < P.npos; p += NT) {
         S.fsf[p] = P.fsf[p];
         const int dy = p / P.fw, dx = p - dy * P.fw;
@@ -1902,31 +1908,45 @@ __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, 
     }
 }
 
+// The <= 4 pending G rows into LDS, in two halves so that the loads can be in
+// flight while the position table is computed (4*Dp <= MH_GP_MAX * NT values).
 // COH (k_mh_flow): the rows were written in THIS launch by workgroups of any
 // XCD -- agent-scope (sc1) loads, never served from a stale L1 line.
+constexpr int MH_GP_MAX = 4;
+
 template <bool COH>
-__device__ __forceinline__ void mh_ws_gp(const MHArgs &P, const MHShared &S, const MHWsItem &I,
-                                         int NT) {
+__device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
+                                              double (&gv)[MH_GP_MAX]) {
     const int Dp = P.Dp;
-    for (int i = threadIdx.x; i < 4 * Dp; i += NT) {
-        const int q = i / Dp, z = i - q * Dp;
-        const int sy = (q >> 1) ? I.psy1 : I.psy0, sx = (q & 1) ? I.psx1 : I.psx0;
-        double gv = 0.0;
-        if (sy >= 0 && sx >= 0) {
-            const double *src = I.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
-            if (COH)
-                gv = __longlong_as_double((long long)__hip_atomic_load(
-                    reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
-                    __HIP_MEMORY_SCOPE_AGENT));
-            else
-                gv = *src;
+#pragma unroll
+    for (int j = 0; j < MH_GP_MAX; ++j) {
+        const int i = threadIdx.x + j * NT;
+        gv[j] = 0.0;
+        if (i < 4 * Dp) {
+            const int q = i / Dp, z = i - q * Dp;
+            const int sy = (q >> 1) ? I.psy1 : I.psy0, sx = (q & 1) ? I.psx1 : I.psx0;
+            if (sy >= 0 && sx >= 0) {
+                const double *src = I.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
+                if (COH)
+                    gv[j] = __longlong_as_double((long long)__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+                else
+                    gv[j] = *src;
+            }
         }
-        S.gp[i] = gv;
     }
 }
 
-// Needs S.pos / S.fsf / S.gp complete (block barrier before the call).  Contains
-// block barriers only when I.real (uniform over the workgroup).
+__device__ __forceinline__ void mh_ws_gp_store(const MHArgs &P, const MHShared &S, int NT,
+                                               const double (&gv)[MH_GP_MAX]) {
+#pragma unroll
+    for (int j = 0; j < MH_GP_MAX; ++j) {
+        const int i = threadIdx.x + j * NT;
+        if (i < 4 * P.Dp) S.gp[i] = gv[j];
+    }
+}
+
 // A virtual item that is a masked spaxel INSIDE the cube has no update: it leaves
 // a zero G row, so that the next colour can apply "every lattice point inside
 // the cube" without looking the mask up (one dependent load less in its setup).
@@ -1943,6 +1963,8 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
     }
 }
 
+// Needs S.pos / S.fsf / S.gp complete (block barrier before the call).  Contains
+// block barriers only when I.real (uniform over the workgroup).
 // COH (k_mh_flow): the residual and the G rows are handed from workgroup to
 // workgroup inside the launch: write-through (sc1) stores and sc1 loads for
 // every such byte, so that neither a release nor an acquire fence is needed
@@ -2095,8 +2117,11 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         mh_ws_zero_row<false>(P, I);
         return;
     }
+    mh_ws_preds(P, I);
+    double gv[MH_GP_MAX];
+    mh_ws_gp_load<false>(P, I, NT, gv);  // in flight while the table is computed
     mh_ws_table(P, S, I, NT);
-    mh_ws_gp<false>(P, S, I, NT);
+    mh_ws_gp_store(P, S, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
     mh_ws_run<NS, UV, false>(P, S, I, sweep, blockIdx.x);
@@ -2212,6 +2237,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     I.Gcur = F.gbuf[(F.pb + k + 1) % 3];
     const bool idle = !I.real && I.prev_cy < 0;  // nothing pending, nothing to do
     bool ok = true;
+    mh_ws_preds(P, I);
     if (!idle) mh_ws_table(P, S, I, NT);
     if (k > 0 && tid < 5) {
         // lanes 0..3: the predecessors (lattice points of colour k-1 whose windows
@@ -2230,13 +2256,15 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
             ok = flow_wait(F.cnt + (k - 2), (unsigned)(prev_off - prev2_off), true, F.err);
         }
     }
-    // every handed-off byte is stored and loaded sc1 (mh_ws_gp<true>,
+    // every handed-off byte is stored and loaded sc1 (mh_ws_gp_load<true>,
     // mh_ws_run<.., true>): no acquire; only keep the loads below the polls
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // a timed-out wait skips the item (*F.err is set: the host reports it)
     if (__syncthreads_or(!ok)) return;
     if (!idle) {
-        mh_ws_gp<true>(P, S, I, NT);
+        double gv[MH_GP_MAX];
+        mh_ws_gp_load<true>(P, I, NT, gv);
+        mh_ws_gp_store(P, S, NT, gv);
         __syncthreads();
         mh_ws_run<NS, UV, true>(P, S, I, sweep, item);
     } else {
