@@ -594,14 +594,22 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV>
-int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+template <bool UV, int U>
+int launch_mh_ws_u(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV>), dim3(grid), dim3(NS + 64), lds,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U>), dim3(grid), dim3(NS + 64), lds,
                        c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// A launch that does not fill the chip (fewer workgroups than 2 per CU) is
+// latency-bound: four window positions in flight per wavefront instead of one.
+template <bool UV>
+int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    if (grid < (unsigned)c->flow_grid / 2) return launch_mh_ws_u<UV, 4>(c, P, grid, sweep);
+    return launch_mh_ws_u<UV, 1>(c, P, grid, sweep);
 }
 
 // One sweep in one launch (k_mh_flow).  P carries the pending colour of the
