@@ -1471,7 +1471,11 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
     double sums[7] = {0, 0, 0, 0, 0, 0, 0};
     const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
     const double Lo = q.a_old * EO;
+    // the uniforms of the Gibbs draw depend on nothing the window pass produces:
+    // drawn here, ahead of the barrier, they are off the critical tail
+    U2 u_gibbs = {0.5, 0.5};
     if (caller) {
+        u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
         double Az = 0.0, Bz = 0.0, Cz = 0.0;
         if (ch < D) {
             for (int gg = 0; gg < G; ++gg) {
@@ -1537,8 +1541,8 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
                 const double ro = P.ra / (1.0 + P.ra * s_ee);
                 const double mu = ro * s_eu;
                 uint32_t blk = BLK_GIBBS;
-                r = truncated_normal(P.min_b[0], P.max_b[0], mu, sqrt(ro), P.seed, q.gsp, sweep,
-                                     &blk);
+                r = truncated_normal<true>(P.min_b[0], P.max_b[0], mu, sqrt(ro), u_gibbs, P.seed,
+                                           q.gsp, sweep, &blk);
             }
             if (lead) {
                 verdict[0] = accept ? 1.0 : 0.0;

@@ -64,8 +64,14 @@ constexpr uint32_t BLK_GIBBS = 2;    // truncated normal: 2, 3, ...
 constexpr double TN_TAIL = 6.0;
 constexpr double SQRT2 = 1.4142135623730951;
 
-// N(0,1) truncated to [alpha, beta]; consumes blocks from *blk upwards.
-__device__ inline double truncated_standard_normal(double alpha, double beta, uint64_t seed,
+// N(0,1) truncated to [alpha, beta]; consumes blocks from *blk upwards.  u0 is
+// the pair of block *blk, drawn by the caller ahead of time (it depends on
+// nothing the window pass produces).  WAVE: every lane of the wavefront calls
+// with the same arguments; the two CDF evaluations then run side by side in the
+// two halves of the wavefront instead of one after the other -- same functions,
+// same arguments, same bits.
+template <bool WAVE>
+__device__ inline double truncated_standard_normal(double alpha, double beta, U2 u0, uint64_t seed,
                                                    uint32_t spaxel, uint32_t sweep,
                                                    uint32_t *blk) {
     double sign = 1.0;
@@ -81,7 +87,8 @@ __device__ inline double truncated_standard_normal(double alpha, double beta, ui
         const double lam = 0.5 * (alpha + sqrt(alpha * alpha + 4.0));
         z = alpha;
         for (int it = 0; it < 1000; ++it) {
-            const U2 u = philox_pair(seed, spaxel, sweep, (*blk)++);
+            const U2 u = (it == 0) ? u0 : philox_pair(seed, spaxel, sweep, *blk);
+            ++*blk;
             const double zz = alpha - log(u.x) / lam;
             if (zz <= beta && log(u.y) <= -0.5 * (zz - lam) * (zz - lam)) {
                 z = zz;
@@ -90,28 +97,41 @@ __device__ inline double truncated_standard_normal(double alpha, double beta, ui
         }
         return sign * z;
     }
-    const U2 u = philox_pair(seed, spaxel, sweep, (*blk)++);
+    ++*blk;
+    const bool upper = WAVE && (__lane_id() & 32);
+    const double x = upper ? beta : alpha;
     if (alpha > 0.0) {
-        const double qa = 0.5 * erfc(alpha / SQRT2);
-        const double qb = 0.5 * erfc(beta / SQRT2);
-        const double q = qa - u.x * (qa - qb);
+        double qa = 0.5 * erfc(x / SQRT2), qb;
+        if (WAVE) {
+            qb = __shfl(qa, 32);
+            qa = __shfl(qa, 0);
+        } else {
+            qb = 0.5 * erfc(beta / SQRT2);
+        }
+        const double q = qa - u0.x * (qa - qb);
         z = SQRT2 * erfcinv(2.0 * q);
     } else {
-        const double pa = normcdf(alpha);
-        const double pb = normcdf(beta);
-        z = normcdfinv(pa + u.x * (pb - pa));
+        double pa = normcdf(x), pb;
+        if (WAVE) {
+            pb = __shfl(pa, 32);
+            pa = __shfl(pa, 0);
+        } else {
+            pb = normcdf(beta);
+        }
+        z = normcdfinv(pa + u0.x * (pb - pa));
     }
     z = fmin(fmax(z, alpha), beta);
     return sign * z;
 }
 
 // TN(lo, hi; mu, sigma): distribution of rtnorm(lo, hi, mu, sigma), lib/rtnorm.py:21-92.
-__device__ inline double truncated_normal(double lo, double hi, double mu, double sigma,
+template <bool WAVE>
+__device__ inline double truncated_normal(double lo, double hi, double mu, double sigma, U2 u0,
                                           uint64_t seed, uint32_t spaxel, uint32_t sweep,
                                           uint32_t *blk) {
     const double alpha = (lo - mu) / sigma;
     const double beta = (hi - mu) / sigma;
-    const double z = truncated_standard_normal(alpha, beta, seed, spaxel, sweep, blk);
+    const double z = truncated_standard_normal<WAVE>(alpha, beta, u0, seed, spaxel, sweep, blk);
     return fmin(fmax(mu + sigma * z, lo), hi);
 }
 

@@ -3,7 +3,7 @@
 """
 Where the time of one k_mh_ws launch goes (needs `make EXPERIMENTS=1`).
 
-    python tools/mh_phases.py [uniform]
+    python tools/mh_phases.py [uniform|full] [workload]
 
 Arms the phase stamps of the library (100 MHz wall clock, five per workgroup:
 entry, setup done, window streamed, prepare wavefront done, update written),
@@ -24,7 +24,8 @@ from deconv3d_amd import _lib  # noqa: E402
 
 def main():
     uniform = len(sys.argv) > 1 and sys.argv[1] == "uniform"
-    D, H, W, fs = bench.WORKLOADS["c3_300x300x128"]
+    workload = sys.argv[2] if len(sys.argv) > 2 else "c3_300x300x128"
+    D, H, W, fs = bench.WORKLOADS[workload]
     fsf, lsf = bench.build_taps(D, fs)
     eng = _lib.Engine((D, H, W), fsf.shape)
     eng.set_taps(fsf, lsf)
@@ -50,7 +51,7 @@ def main():
         n = 0
         # work-list length of this colour: real + virtual positions
         col = launch % ncol
-        n = 28 * 28 + 64
+        n = (H // fsf.shape[0] + 3) * (W // fsf.shape[1] + 3)
         buf = np.zeros(n * 8, dtype=np.uint64)
         assert lib.d3d_x_stamps_read(eng._ctx, launch, n, buf.ctypes.data_as(
             C.POINTER(C.c_uint64))) == 0
@@ -85,8 +86,8 @@ def main():
     names = ["workgroups", "real", "last entry", "setup done (med)", "stream done (med)",
              "stream done (last)", "prepare done (med)", "last update written",
              "next launch starts"]
-    print("k_mh_ws phases, %s variance, us from the first workgroup's entry "
-          "(median over %d launches)" % ("uniform" if uniform else "per-voxel", len(t)))
+    print("k_mh_ws phases, %s, %s variance, us from the first workgroup's entry "
+          "(median over %d launches)" % (workload, "uniform" if uniform else "per-voxel", len(t)))
     for i, nm in enumerate(names):
         print("  %-22s %8.2f   (min %.2f, max %.2f)" % (nm, np.median(t[:, i]), t[:, i].min(),
                                                         t[:, i].max()))
