@@ -258,7 +258,7 @@ def main():
     roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, false>", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, false,", args.workload),
                 "bytes_per_launch": bytes_per_sweep // ncol,
                 "avg_launch_us": round(avg_launch_us, 2), "launches": launches}
 
@@ -343,7 +343,7 @@ def main():
                 "bytes_per_launch": bytes_per_sweep * 2 // 3 // ncol,
                 "avg_launch_us": round(u_us, 2), "achieved": round(u_gbs, 1),
                 "frac": round(u_gbs / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, true>", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, true,", args.workload),
                 "note": "extra: reference default variance=None (one constant); not `value`"}
 
     if rank == 0 and not args.no_cpu:
