@@ -12,7 +12,7 @@ from bench import WORKLOADS, build_taps, synthetic_inputs  # noqa: E402
 from deconv3d_amd import _lib  # noqa: E402
 
 n_sweeps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-chunk = 250
+chunk = 250 if n_sweeps <= 5000 else 1000
 D, H, W, fs = WORKLOADS["c3_300x300x128"]
 fsf, lsf = build_taps(D, fs)
 eng = _lib.Engine((D, H, W), fsf.shape)
