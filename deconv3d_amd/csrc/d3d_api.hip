@@ -132,6 +132,7 @@ struct d3d_ctx {
     bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
+    int spectral_shfl = 0;        // D3D_SPECTRAL_SHFL=1: wavefront shuffles instead of the LDS window
     int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
     int march_hy = 16;            // output rows per strip of the march kernel
     int zmajor_hy = 32;           // output rows per strip of the z-major spatial kernel
@@ -235,6 +236,12 @@ int launch_spectral(d3d_ctx *c, const double *in, double *out) {
         // dense +-LSF_RL taps, spectrum within one wavefront: streaming form
         const int NT = 256, G = NT / c->HL;
         const unsigned grid = (unsigned)((c->HW + G - 1) / G);
+        if (c->spectral_shfl && c->HL == 64) {  // neighbours by wavefront shuffles, no LDS
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral_shfl<256>), dim3(grid), dim3(NT), 0,
+                               c->stream, c->Dp, c->HW, (const double *)c->lsf_dense, in, out);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         const size_t lds = (size_t)G * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral_dense<256>), dim3(grid), dim3(NT), lds,
                            c->stream, c->Dp, c->HL, c->HW, (const double *)c->lsf_dense, in, out);
@@ -1089,6 +1096,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     c->lsf_dense_ok = false;
     if (const char *e = getenv("D3D_FUSE_LSF")) c->fuse_lsf = atoi(e);
     if (const char *e = getenv("D3D_SPECTRAL_DENSE")) c->spectral_dense = atoi(e);
+    if (const char *e = getenv("D3D_SPECTRAL_SHFL")) c->spectral_shfl = atoi(e);
     if (c->ntaps && c->N == c->D && c->D >= 4 * d3d::LSF_RL) {
         std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
         bool ok = true;

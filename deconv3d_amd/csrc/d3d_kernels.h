@@ -237,6 +237,41 @@ __global__ __launch_bounds__(NT) void k_spectral_dense(int Dp, int HL, long nspa
     *reinterpret_cast<double2 *>(out + sp * Dp + 2 * zl) = acc;
 }
 
+// The same pass with wavefront shuffles instead of the LDS window (HL == 64: one
+// spectrum per wavefront, so the circular wrap is the wrap of the lane index):
+// lane l needs channels 2l-8 .. 2l+9, i.e. both components of lanes l-4 .. l+4,
+// fetched with ds_bpermute (__shfl).  Measured against the LDS form on MI355X
+// (D3D_SPECTRAL_SHFL=1): both run at the streaming rate of the part; the pass is
+// bound by HBM, not by how the neighbours are exchanged.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_spectral_shfl(int Dp, long nspax,
+                                                      const double *__restrict__ wl,
+                                                      const double *__restrict__ in,
+                                                      double *__restrict__ out) {
+    constexpr int RL = LSF_RL;
+    constexpr int G = NT / 64;
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long sp = (long)blockIdx.x * G + g;
+    if (sp >= nspax) return;
+    const double2 v = *reinterpret_cast<const double2 *>(in + sp * Dp + 2 * lane);
+    // w[j] = channel 2*lane - RL + j, j = 0 .. 2*RL + 1
+    double w[2 * RL + 2];
+#pragma unroll
+    for (int m = -RL / 2; m <= RL / 2; ++m) {
+        const int src = (lane + m) & 63;
+        w[RL + 2 * m] = (m == 0) ? v.x : __shfl(v.x, src);
+        w[RL + 2 * m + 1] = (m == 0) ? v.y : __shfl(v.y, src);
+    }
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < 2 * RL + 1; ++j) {
+        const double t = wl[j];
+        acc.x = fma(t, w[j], acc.x);
+        acc.y = fma(t, w[j + 1], acc.y);
+    }
+    *reinterpret_cast<double2 *>(out + sp * Dp + 2 * lane) = acc;
+}
+
 // ------------------------------------------------------------------------- //
 // spatial (FSF) pass: true 2-D convolution, zero boundary, 'same' size        //
 // (scipy.signal.convolve2d(..., mode='same') of lib/run.py:1027-1029)         //

@@ -102,6 +102,28 @@ def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
     assert not np.array_equal(outs[0], outs[1])      # two different summation orders did run
 
 
+def test_spectral_pass_by_wavefront_shuffles_is_bit_identical(monkeypatch):
+    """D3D_SPECTRAL_SHFL=1: the dense LSF pass exchanges neighbouring channels
+    with wavefront shuffles instead of the wave-private LDS window (depth 128: one
+    spectrum per wavefront).  Same taps, same order: same bits."""
+    from deconv3d_amd import _lib
+    shape = (128, 9, 11)
+    rng = np.random.default_rng(8)
+    cube = rng.normal(size=shape)
+    lsf = O.muse_like_lsf(128)
+    fsf = np.ones((1, 1))
+    outs = []
+    for knob in ("0", "1"):
+        monkeypatch.setenv("D3D_SPECTRAL_SHFL", knob)
+        with _lib.Engine(shape, fsf.shape) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.upload_slot(_lib.SLOT_TMP0, cube)
+            eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+            outs.append(eng.download_slot(_lib.SLOT_SIM))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert_cube_close(outs[1], O.convolve_cube(cube, fsf, lsf), "shuffle LSF pass vs oracle")
+
+
 def test_reference_saved_cube_pair_on_device():
     """The reference's own saved pair (tests/golden/ref_galpak_pair.npz, see
     tests/test_oracle.py): the HIP convolution of its clean cube under the MUSE
