@@ -101,8 +101,13 @@ struct d3d_ctx {
     bool ivar_is_uniform = false; // SLOT_IVAR holds one constant (k_mh_ws<.., true> skips reading it)
     double ivar_uniform = 0.0;
     bool uniform_fast_path = true;  // D3D_UNIFORM_IVAR=0 turns the variant off
-    double *gbuf[3] = {nullptr, nullptr, nullptr};  // update coefficients [slots][Dp]
-    int gpend = 0;                // gbuf[gpend] holds the pending updates
+    double *gbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // update coefficients [slots][Dp]
+    // pending layers, oldest first: colour class and G buffer of each update that has
+    // not been written into SLOT_ERR yet (k_mh_ws applies up to mh_layers of them)
+    int lay_n = 0, lay_cy[3] = {-1, -1, -1}, lay_cx[3] = {-1, -1, -1}, lay_g[3] = {0, 0, 0};
+    int mh_layers = 2;            // pending layers in use (1: write the residual back every colour)
+    int mh_layers_cfg = 2;        // D3D_MH_LAYERS=1|2|3; small cubes fall back to 1 unless it is set
+    bool mh_layers_forced = false;
     // dataflow kernel (k_mh_flow): one launch per sweep
     int mh_flow = 0;              // D3D_MH_FLOW=1: one launch per sweep (k_mh_flow; measured
                                   // slower than one k_mh_ws launch per colour: DESIGN.md)
@@ -114,7 +119,6 @@ struct d3d_ctx {
     unsigned *flow_state = nullptr;  // one block, zeroed per launch: ctl[4] | cnt[K] | done[items]
     unsigned *flow_err = nullptr;    // sticky error word of k_mh_flow
     size_t flow_state_bytes = 0, flow_cap_items = 0, flow_cap_K = 0;
-    int pend_cy = -1, pend_cx = -1;  // colour class of the pending updates (-1: none)
     int slots_x = 0, slots = 0;
     int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
     bool tiled = false;              // d3d_set_tile was called
@@ -503,9 +507,28 @@ int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data
     }
 }
 
+void pend_clear(d3d_ctx *c) { c->lay_n = 0; }
+
+// a G buffer that holds no pending layer
+int pend_free_buf(const d3d_ctx *c) {
+    for (int b = 0; b < 4; ++b) {
+        bool used = false;
+        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
+        if (!used) return b;
+    }
+    return 0;  // unreachable: at most 3 layers
+}
+
+void pend_push(d3d_ctx *c, int cy, int cx, int g) {
+    c->lay_cy[c->lay_n] = cy;
+    c->lay_cx[c->lay_n] = cx;
+    c->lay_g[c->lay_n] = g;
+    ++c->lay_n;
+}
+
 // params -> SLOT_TMP0 (LSF lines) -> dst (sim, or residual when resid)
 int forward_into(d3d_ctx *c, double *dst, bool resid) {
-    if (resid) c->pend_cy = c->pend_cx = -1;  // a fresh residual supersedes pending updates
+    if (resid) pend_clear(c);  // a fresh residual supersedes pending updates
     int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 1);
     if (rc) return rc;
     return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, resid ? c->slot[D3D_SLOT_DATA] : nullptr);
@@ -544,10 +567,20 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.gx0 = c->gx0;
     P.Wg = c->Wg;
     P.mask = c->mask;
-    P.Gprev = c->gbuf[c->gpend];
-    P.Gcur = c->gbuf[(c->gpend + 1) % 3];
-    P.prev_cy = c->pend_cy;
-    P.prev_cx = c->pend_cx;
+    P.n_lay = c->lay_n;
+    P.write_back = 1;
+    for (int j = 0; j < 3; ++j) {
+        const bool live = j < c->lay_n;
+        P.lay_cy[j] = live ? c->lay_cy[j] : -1;
+        P.lay_cx[j] = live ? c->lay_cx[j] : -1;
+        P.lay_G[j] = c->gbuf[live ? c->lay_g[j] : 0];
+    }
+    P.Gcur = c->gbuf[pend_free_buf(c)];
+    // the kernels that keep one pending layer (k_mh_defer, k_mh_flow) see the newest
+    const int last = c->lay_n - 1;
+    P.Gprev = c->gbuf[last >= 0 ? c->lay_g[last] : 0];
+    P.prev_cy = last >= 0 ? c->lay_cy[last] : -1;
+    P.prev_cx = last >= 0 ? c->lay_cx[last] : -1;
     P.slots_x = c->slots_x;
     P.ext_idx = nullptr;
     P.ext_in = nullptr;
@@ -601,11 +634,11 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV, int U>
-int launch_mh_ws_u(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+template <bool UV, int U, int M>
+int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     constexpr int NS = 256;
-    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U>), dim3(grid), dim3(NS + 64), lds,
+    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M>), dim3(grid), dim3(NS + 64), lds,
                        c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -613,10 +646,21 @@ int launch_mh_ws_u(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t swe
 
 // A launch that does not fill the chip (fewer workgroups than 2 per CU) is
 // latency-bound: four window positions in flight per wavefront instead of one.
+// The kernel for up to MH_LAYERS pending layers needs more LDS; with one layer
+// configured the lean variant runs.
 template <bool UV>
 int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    if (grid < (unsigned)c->flow_grid / 2) return launch_mh_ws_u<UV, 4>(c, P, grid, sweep);
-    return launch_mh_ws_u<UV, 1>(c, P, grid, sweep);
+    const bool small = grid < (unsigned)c->flow_grid / 2;
+    if (c->mh_layers >= 3) {
+        if (small) return launch_mh_ws_um<UV, 4, 3>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 1, 3>(c, P, grid, sweep);
+    }
+    if (c->mh_layers == 2) {
+        if (small) return launch_mh_ws_um<UV, 4, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 1, 2>(c, P, grid, sweep);
+    }
+    if (small) return launch_mh_ws_um<UV, 4, 1>(c, P, grid, sweep);
+    return launch_mh_ws_um<UV, 1, 1>(c, P, grid, sweep);
 }
 
 // One sweep in one launch (k_mh_flow).  P carries the pending colour of the
@@ -648,16 +692,15 @@ int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
     F.K = c->flow_K;
     F.LY = c->flow_LY;
     F.LX = c->flow_LX;
-    F.pb = c->gpend;
+    F.pb = c->lay_n ? c->lay_g[c->lay_n - 1] : 0;  // (one layer at most: launch_mh_flow's caller)
     F.items = c->flow_items;
     F.epoch = 1;
     const int rc = (c->ivar_is_uniform && c->uniform_fast_path)
                        ? launch_mh_flow_t<true>(c, P, F, sweep)
                        : launch_mh_flow_t<false>(c, P, F, sweep);
     if (rc) return rc;
-    c->gpend = (c->gpend + c->flow_K) % 3;
-    c->pend_cy = c->flow_last_cy;
-    c->pend_cx = c->flow_last_cx;
+    pend_clear(c);
+    pend_push(c, c->flow_last_cy, c->flow_last_cx, (F.pb + c->flow_K) % 3);
     return 0;
 }
 
@@ -678,7 +721,7 @@ int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
 
 // Write the pending (deferred) residual updates into SLOT_ERR.
 int flush_pending(d3d_ctx *c) {
-    if (c->pend_cy < 0) return 0;
+    if (c->lay_n == 0) return 0;
     d3d::MHArgs P;
     fill_mh_args(c, P);
     const int NT = 256;
@@ -692,7 +735,7 @@ int flush_pending(d3d_ctx *c) {
                            dim3(1024), 0, c->stream, P);
     }
     HIP_TRY(hipGetLastError());
-    c->pend_cy = c->pend_cx = -1;
+    pend_clear(c);
     return 0;
 }
 
@@ -727,6 +770,16 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
+    // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
+    // two registers per thread (Dp <= 160); the other MH kernels keep one layer
+    if (const char *e = getenv("D3D_MH_LAYERS")) {
+        c->mh_layers_cfg = atoi(e);
+        c->mh_layers_forced = true;
+    }
+    if (c->mh_layers_cfg < 1) c->mh_layers_cfg = 1;
+    if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
+    if (c->mh_defer != 1 || c->mh_flow || c->Dp > 160) c->mh_layers_cfg = 1;
+    c->mh_layers = c->mh_layers_cfg;
 }
 
 int build_colour_lists(d3d_ctx *c) {
@@ -765,6 +818,14 @@ int build_colour_lists(d3d_ctx *c) {
         }
     c->colour_off[ncol] = (int)list.size();
     if (list.size() > c->spx_cap) return fail(D3D_ERR_HIP, "internal: colour list overflow");
+    // Launches that do not fill the chip are latency chains: a second layer only adds
+    // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
+    {
+        int most = 0;
+        for (int col = 0; col < ncol; ++col)
+            most = std::max(most, c->colour_off[col + 1] - c->colour_off[col]);
+        c->mh_layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
+    }
     // tables of the dataflow kernel: active colours in order, their ticket
     // ranges, and per colour the map lattice point -> index in its list
     c->flow_K = 0;
@@ -933,7 +994,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->prev, (size_t)c->HW * 3 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->recbuf, (size_t)c->HW * 8 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->idxbuf, (size_t)c->HW * sizeof(int)));
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < 4; ++b) {
         CTX_TRY(hipMalloc(&c->gbuf[b], (size_t)c->slots * c->Dp * sizeof(double)));
         CTX_TRY(hipMemsetAsync(c->gbuf[b], 0, (size_t)c->slots * c->Dp * sizeof(double), c->stream));
     }
@@ -971,7 +1032,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
-                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2],
+                    c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
     for (void *p : ptrs)
@@ -1126,7 +1187,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_taps = true;
     c->err_valid = false;
-    c->pend_cy = c->pend_cx = -1;
+    pend_clear(c);
     return D3D_OK;
 }
 
@@ -1185,7 +1246,7 @@ int d3d_set_data(d3d_ctx *c, const double *data, const double *var, double var_s
     if (rc) return rc;
     c->have_data = true;
     c->err_valid = false;
-    c->pend_cy = c->pend_cx = -1;
+    pend_clear(c);
     return D3D_OK;
 }
 
@@ -1197,7 +1258,7 @@ int d3d_set_params(d3d_ctx *c, const double *params) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_params = true;
     c->err_valid = false;
-    c->pend_cy = c->pend_cx = -1;
+    pend_clear(c);
     return D3D_OK;
 }
 
@@ -1251,7 +1312,7 @@ int d3d_upload_slot(d3d_ctx *c, int slot, const double *cube) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (slot == D3D_SLOT_ERR) {
         c->err_valid = true;
-        c->pend_cy = c->pend_cx = -1;
+        pend_clear(c);
     }
     if (slot == D3D_SLOT_IVAR) c->ivar_is_uniform = false;
     return D3D_OK;
@@ -1462,11 +1523,15 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                     (size_t)n_all * 8 <= c->stamp_stride)
                     P.stamp = c->stampbuf + (c->stamp_next++) * c->stamp_stride;
 #endif
+                // the launch that finds mh_layers layers pending applies them for good
+                P.write_back = (c->lay_n >= c->mh_layers) ? 1 : 0;
+                const int g_cur = pend_free_buf(c);
                 int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
                 if (rc) return rc;
-                c->gpend = (c->gpend + 1) % 3;  // this launch's updates are now the pending ones
-                c->pend_cy = ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
-                c->pend_cx = ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw;
+                if (P.write_back) pend_clear(c);
+                // this launch's updates are the newest pending layer (local residues)
+                pend_push(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
+                          ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw, g_cur);
             } else {
                 int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s);
                 if (rc) return rc;
@@ -1563,7 +1628,7 @@ int d3d_set_tile(d3d_ctx *c, int gy0, int gx0, int Wg, int oy0, int oy1, int ox0
     c->ox0 = ox0;
     c->ox1 = ox1;
     c->tiled = true;
-    c->pend_cy = c->pend_cx = -1;
+    pend_clear(c);
     if (c->have_data) return build_colour_lists(c);
     return D3D_OK;
 }

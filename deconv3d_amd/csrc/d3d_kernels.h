@@ -1345,6 +1345,12 @@ struct MHArgs {
     const uint8_t *mask;  // [H*W], 1 = spaxel is iterated
     const double *Gprev;  // [slots][Dp] pending updates of colour prev_colour
     double *Gcur;         // [slots][Dp] this launch's updates
+    // k_mh_ws: up to MH_LAYERS pending colours, oldest first (see "several pending
+    // layers" below); prev_cy / prev_cx / Gprev above describe the only layer for
+    // the kernels that keep a single one
+    int n_lay, write_back;
+    int lay_cy[3], lay_cx[3];
+    const double *lay_G[3];
     int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
     int slots_x;          // slot(y,x) = (y/fh)*slots_x + x/fw
     // external-lines mode (d3d_mh_colour_lines: a python LineModel evaluated on
@@ -1381,11 +1387,14 @@ struct MHArgs {
 #define D3D_MH_STAMP(at, k, who)
 #endif
 
-__host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos) {
+constexpr int MH_LAYERS = 3;  // pending colours k_mh_ws can apply in one pass
+
+__host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos,
+                                                 int M = 1) {
     const int G = NT / HL;
-    // taps | position table (3 ints per position, as doubles) | 4 pending G rows |
-    // group partial sums | two unit lines | G | block sums
-    return (size_t)npos + 2 * (size_t)npos + 4 * (size_t)Dp + (size_t)G * 3 * Dp +
+    // taps | position table (1 + M ints per position, in (1+M) doubles) | 4 pending
+    // G rows per layer | group partial sums | two unit lines | G | block sums
+    return (size_t)npos + (size_t)(1 + M) * npos + 4 * (size_t)M * Dp + (size_t)G * 3 * Dp +
            2 * (size_t)N + Dp + 8 * (NT / 64) + 8;
 }
 
@@ -1395,13 +1404,13 @@ struct MHShared {
 };
 
 __device__ __forceinline__ MHShared mh_carve(double *smem, int NT, int HL, int Dp, int N,
-                                              int npos) {
+                                              int npos, int M = 1) {
     MHShared S;
     const int G = NT / HL;
     S.fsf = smem;
-    S.pos = reinterpret_cast<int *>(S.fsf + npos);  // 3 ints per position
-    S.gp = S.fsf + 3 * (size_t)npos;
-    S.red = S.gp + 4 * (size_t)Dp;
+    S.pos = reinterpret_cast<int *>(S.fsf + npos);  // 1 + M ints per position
+    S.gp = S.fsf + (size_t)(2 + M) * npos;
+    S.red = S.gp + 4 * (size_t)M * Dp;
     S.gO = S.red + (size_t)G * 3 * Dp;
     S.gN = S.gO + N;
     S.G = S.gN + N;
@@ -1883,8 +1892,9 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
 // four workgroups per CU, so that every window of a colour launch is resident
 // at once.  Same arithmetic, same summation order, bit-identical results as
 // k_mh_defer.
-__host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int N, int npos) {
-    return mh_lds_doubles(NS, HL, Dp, N, npos) + (size_t)Dp + 16;
+__host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int N, int npos,
+                                                    int M = 1) {
+    return mh_lds_doubles(NS, HL, Dp, N, npos, M) + (size_t)Dp + 16;
 }
 
 // UV = true: the 1/variance cube is one constant (the reference's default when
@@ -1892,97 +1902,144 @@ __host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int 
 // threads take it from P.ivar_uniform instead of reading SLOT_IVAR -- 16 instead
 // of 24 bytes per window voxel, same arithmetic, bit-identical results.
 //
-// The workgroup's work on one window, in three steps shared by k_mh_ws (one
-// launch per colour) and k_mh_flow (one launch per sweep):
-//   mh_ws_table  position table + taps into LDS (geometry and mask only)
-//   mh_ws_gp     the <= 4 pending G rows of the previous colour into LDS
-//   mh_ws_run    window pass + prepare wavefront + decision + G row out
+// The workgroup's work on one window, in steps shared by k_mh_ws (one launch per
+// colour) and k_mh_flow (one launch per sweep):
+//   mh_ws_preds    the <= 2 x 2 spaxels of every pending colour that cover the window
+//   mh_ws_table    position table + taps into LDS (geometry only)
+//   mh_ws_gp_*     their G rows into LDS
+//   mh_ws_run      window pass + prepare wavefront + decision + G row out
+//
+// Several pending layers (template capacity M, I.n_lay <= M in use).  Writing the
+// residual costs about twice what reading it does on this part (the uniform-
+// variance variant, half reads and half writes, streams at 4.6 TB/s where the
+// general one reaches 5.7).  So the pass need not write e + f G back after every
+// colour: up to M colours stay pending as (colour, G rows) layers, a launch
+// applies them in registers, oldest first -- the same fma sequence as if each had
+// been written back in turn, so the chain stays bit-identical -- and only the
+// launch that finds M layers pending stores the result and starts over.  One
+// residual write per M colours instead of one per colour.
 struct MHWsItem {
     int y, x, real;
-    int prev_cy, prev_cx;  // colour class of the pending updates, -1 = none
-    int psy0, psy1, psx0, psx1;  // the <= 2 x 2 pending spaxels that cover this window
-                                 // (scalars: a dynamically indexed array lands in scratch)
-    const double *Gprev;
+    int n_lay, write_back;
+    int lay_cy[MH_LAYERS], lay_cx[MH_LAYERS];  // colour class of each pending layer
+    // the <= 2 x 2 spaxels of layer j that cover this window (-1 = none).  Only ever
+    // indexed with compile-time constants: a dynamic index would put it in scratch.
+    int psy0[MH_LAYERS], psy1[MH_LAYERS], psx0[MH_LAYERS], psx1[MH_LAYERS];
+    const double *lay_G[MH_LAYERS];
     double *Gcur;
 };
 
+// Item header from the launch arguments (k_mh_ws: every workgroup the same layers).
+__device__ __forceinline__ void mh_ws_layers_from_args(const MHArgs &P, MHWsItem &I) {
+    I.n_lay = P.n_lay;
+    I.write_back = P.write_back;
+#pragma unroll
+    for (int j = 0; j < MH_LAYERS; ++j) {
+        I.lay_cy[j] = P.lay_cy[j];
+        I.lay_cx[j] = P.lay_cx[j];
+        I.lay_G[j] = P.lay_G[j];
+    }
+    I.Gcur = P.Gcur;
+}
+
+template <int M>
 __device__ __forceinline__ void mh_ws_preds(const MHArgs &P, MHWsItem &I) {
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     const int y = I.y, x = I.x;
-    if (I.prev_cy >= 0) {
-        I.psy0 = covering_coord(max(y - fhh, 0), I.prev_cy, P.fh, fhh, P.H);
-        I.psy1 = covering_coord(min(y + fhh, P.H - 1), I.prev_cy, P.fh, fhh, P.H);
-        I.psx0 = covering_coord(max(x - fhw, 0), I.prev_cx, P.fw, fhw, P.W);
-        I.psx1 = covering_coord(min(x + fhw, P.W - 1), I.prev_cx, P.fw, fhw, P.W);
-    } else {
-        I.psy0 = I.psy1 = I.psx0 = I.psx1 = -1;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        if (j < I.n_lay) {
+            I.psy0[j] = covering_coord(max(y - fhh, 0), I.lay_cy[j], P.fh, fhh, P.H);
+            I.psy1[j] = covering_coord(min(y + fhh, P.H - 1), I.lay_cy[j], P.fh, fhh, P.H);
+            I.psx0[j] = covering_coord(max(x - fhw, 0), I.lay_cx[j], P.fw, fhw, P.W);
+            I.psx1[j] = covering_coord(min(x + fhw, P.W - 1), I.lay_cx[j], P.fw, fhw, P.W);
+        } else {
+            I.psy0[j] = I.psy1[j] = I.psx0[j] = I.psx1[j] = -1;
+        }
     }
 }
 
-// needs mh_ws_preds
+// needs mh_ws_preds.  Table row of position p: [0] local spaxel index of the voxel
+// column (-1 = outside the cube); [1+j] for layer j: tap index of that layer's
+// update there | which of its <= 4 staged G rows << 16, or -1 = none.
+template <int M>
 __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                             int NT) {
+    constexpr int ROW = 1 + M;
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     const int y = I.y, x = I.x;
     for (int p = threadIdx.x; p < P.npos; p += NT) {
         S.fsf[p] = P.fsf[p];
         const int dy = p / P.fw, dx = p - dy * P.fw;
         const int yy = y + dy - fhh, xx = x + dx - fhw;
-        int vox = -1, tap = -1, sel = 0;
-        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
-            vox = yy * P.W + xx;
-            if (I.prev_cy >= 0) {
-                const int sy = covering_coord(yy, I.prev_cy, P.fh, fhh, P.H);
-                const int sx = covering_coord(xx, I.prev_cx, P.fw, fhw, P.W);
-                // (a masked spaxel there left a zero G row: see mh_ws_run)
+        const bool inside = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+        S.pos[ROW * p] = inside ? yy * P.W + xx : -1;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            int code = -1;
+            if (inside && j < I.n_lay) {
+                const int sy = covering_coord(yy, I.lay_cy[j], P.fh, fhh, P.H);
+                const int sx = covering_coord(xx, I.lay_cx[j], P.fw, fhw, P.W);
+                // (a masked spaxel there left a zero G row: see mh_ws_zero_row)
+                if (sy >= 0 && sx >= 0)
+                    code = ((yy - sy + fhh) * P.fw + (xx - sx + fhw)) |
+                           (((sy == I.psy0[j] ? 0 : 2) + (sx == I.psx0[j] ? 0 : 1)) << 16);
+            }
+            S.pos[ROW * p + 1 + j] = code;
+        }
+    }
+}
+
+// The <= 4 pending G rows of every layer into LDS (S.gp[j][q][Dp]), in two halves
+// so that the loads can be in flight while the position table is computed
+// (4*Dp <= MH_GP_K * NT values per layer: checked by the launcher).
+// COH (k_mh_flow): the rows were written in THIS launch by workgroups of any
+// XCD -- agent-scope (sc1) loads, never served from a stale L1 line.
+template <int M>
+struct MHGpRegs {
+    static constexpr int K = (M == 1) ? 4 : 2;
+    double v[M][K];
+};
+
+template <int M, bool COH>
+__device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
+                                              MHGpRegs<M> &R) {
+    const int Dp = P.Dp;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+#pragma unroll
+        for (int k = 0; k < MHGpRegs<M>::K; ++k) {
+            const int i = threadIdx.x + k * NT;
+            R.v[j][k] = 0.0;
+            if (j < I.n_lay && i < 4 * Dp) {
+                const int q = i / Dp, z = i - q * Dp;
+                const int sy = (q >> 1) ? I.psy1[j] : I.psy0[j];
+                const int sx = (q & 1) ? I.psx1[j] : I.psx0[j];
                 if (sy >= 0 && sx >= 0) {
-                    tap = (yy - sy + fhh) * P.fw + (xx - sx + fhw);
-                    sel = (sy == I.psy0 ? 0 : 2) + (sx == I.psx0 ? 0 : 1);
+                    const double *src =
+                        I.lay_G[j] + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
+                    if (COH)
+                        R.v[j][k] = __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT));
+                    else
+                        R.v[j][k] = *src;
                 }
             }
         }
-        S.pos[3 * p + 0] = vox;
-        S.pos[3 * p + 1] = tap;
-        S.pos[3 * p + 2] = sel;
     }
 }
 
-// The <= 4 pending G rows into LDS, in two halves so that the loads can be in
-// flight while the position table is computed (4*Dp <= MH_GP_MAX * NT values).
-// COH (k_mh_flow): the rows were written in THIS launch by workgroups of any
-// XCD -- agent-scope (sc1) loads, never served from a stale L1 line.
-constexpr int MH_GP_MAX = 4;
-
-template <bool COH>
-__device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
-                                              double (&gv)[MH_GP_MAX]) {
-    const int Dp = P.Dp;
+template <int M>
+__device__ __forceinline__ void mh_ws_gp_store(const MHArgs &P, const MHShared &S, const MHWsItem &I,
+                                               int NT, const MHGpRegs<M> &R) {
 #pragma unroll
-    for (int j = 0; j < MH_GP_MAX; ++j) {
-        const int i = threadIdx.x + j * NT;
-        gv[j] = 0.0;
-        if (i < 4 * Dp) {
-            const int q = i / Dp, z = i - q * Dp;
-            const int sy = (q >> 1) ? I.psy1 : I.psy0, sx = (q & 1) ? I.psx1 : I.psx0;
-            if (sy >= 0 && sx >= 0) {
-                const double *src = I.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
-                if (COH)
-                    gv[j] = __longlong_as_double((long long)__hip_atomic_load(
-                        reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
-                        __HIP_MEMORY_SCOPE_AGENT));
-                else
-                    gv[j] = *src;
-            }
+    for (int j = 0; j < M; ++j) {
+#pragma unroll
+        for (int k = 0; k < MHGpRegs<M>::K; ++k) {
+            const int i = threadIdx.x + k * NT;
+            if (j < I.n_lay && i < 4 * P.Dp) S.gp[(size_t)j * 4 * P.Dp + i] = R.v[j][k];
         }
-    }
-}
-
-__device__ __forceinline__ void mh_ws_gp_store(const MHArgs &P, const MHShared &S, int NT,
-                                               const double (&gv)[MH_GP_MAX]) {
-#pragma unroll
-    for (int j = 0; j < MH_GP_MAX; ++j) {
-        const int i = threadIdx.x + j * NT;
-        if (i < 4 * P.Dp) S.gp[i] = gv[j];
     }
 }
 
@@ -2008,9 +2065,10 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
 // workgroup inside the launch: write-through (sc1) stores and sc1 loads for
 // every such byte, so that neither a release nor an acquire fence is needed
 // (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
-template <int NS, bool UV, bool COH, int U>
+template <int NS, bool UV, bool COH, int U, int M>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                           uint32_t sweep, long stamp_at) {
+    constexpr int ROW = 1 + M;
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp, N = P.N;
     const int G = NS / HL;
@@ -2048,7 +2106,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int p = p0 + u * G;
-                    vox[u] = (p < P.npos) ? S.pos[3 * p + 0] : -1;
+                    vox[u] = (p < P.npos) ? S.pos[ROW * p] : -1;
                     const long idx = (long)max(vox[u], 0) * Dp + 2 * zl;
                     if (COH) {
                         cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
@@ -2063,14 +2121,22 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                 for (int u = 0; u < U; ++u) {
                     if (vox[u] < 0) continue;
                     const int p = p0 + u * G;
-                    const int tap = S.pos[3 * p + 1];
                     const long idx = (long)vox[u] * Dp + 2 * zl;
-                    if (tap >= 0) {
-                        const double fp = S.fsf[tap];
-                        const double2 gz = *reinterpret_cast<const double2 *>(
-                            S.gp + S.pos[3 * p + 2] * Dp + 2 * zl);
-                        e[u].x = fma(fp, gz.x, e[u].x);
-                        e[u].y = fma(fp, gz.y, e[u].y);
+                    // the pending layers, oldest first: e <- e + f G of each
+                    bool touched = false;
+#pragma unroll
+                    for (int j = 0; j < M; ++j) {
+                        const int code = (j < I.n_lay) ? S.pos[ROW * p + 1 + j] : -1;
+                        if (code >= 0) {
+                            const double fp = S.fsf[code & 0xffff];
+                            const double2 gz = *reinterpret_cast<const double2 *>(
+                                S.gp + ((size_t)j * 4 + (code >> 16)) * Dp + 2 * zl);
+                            e[u].x = fma(fp, gz.x, e[u].x);
+                            e[u].y = fma(fp, gz.y, e[u].y);
+                            touched = true;
+                        }
+                    }
+                    if (touched && I.write_back) {
                         if (COH) {
                             cv.d = e[u];
                             __builtin_amdgcn_raw_buffer_store_b128(cv.i, err_rsrc, (int)(idx * 8), 0,
@@ -2139,33 +2205,31 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     D3D_MH_STAMP(stamp_at, 4, 0);
 }
 
-template <int NS, bool UV, int U>
+template <int NS, bool UV, int U, int M>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
-    const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos);
+    const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
     D3D_MH_STAMP(blockIdx.x, 0, 0);
     const int4 ent = P.spx[blockIdx.x];
     MHWsItem I;
     I.y = ent.x;  // may lie outside the cube when virtual
     I.x = ent.y;
     I.real = ent.z;
-    I.prev_cy = P.prev_cy;
-    I.prev_cx = P.prev_cx;
-    I.Gprev = P.Gprev;
-    I.Gcur = P.Gcur;
-    if (!I.real && I.prev_cy < 0) {  // nothing pending, nothing to apply
+    mh_ws_layers_from_args(P, I);
+    // a virtual position only matters to a launch that writes the residual back
+    if (!I.real && (I.n_lay == 0 || !I.write_back)) {
         mh_ws_zero_row<false>(P, I);
         return;
     }
-    mh_ws_preds(P, I);
-    double gv[MH_GP_MAX];
-    mh_ws_gp_load<false>(P, I, NT, gv);  // in flight while the table is computed
-    mh_ws_table(P, S, I, NT);
-    mh_ws_gp_store(P, S, NT, gv);
+    mh_ws_preds<M>(P, I);
+    MHGpRegs<M> gv;
+    mh_ws_gp_load<M, false>(P, I, NT, gv);  // in flight while the table is computed
+    mh_ws_table<M>(P, S, I, NT);
+    mh_ws_gp_store<M>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
-    mh_ws_run<NS, UV, false, U>(P, S, I, sweep, blockIdx.x);
+    mh_ws_run<NS, UV, false, U, M>(P, S, I, sweep, blockIdx.x);
 }
 
 // ---- one launch per sweep: dataflow over the colour classes ----------------
@@ -2264,31 +2328,40 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     I.x = ent.y;
     I.real = ent.z;
     int prev_off = 0, prev2_off = 0;
+    int prev_cy, prev_cx;
     if (k > 0) {
         const int4 pc = F.col[k - 1];
-        I.prev_cy = pc.y;
-        I.prev_cx = pc.z;
+        prev_cy = pc.y;
+        prev_cx = pc.z;
         prev_off = pc.x;
         if (k > 1) prev2_off = F.col[k - 2].x;
     } else {
-        I.prev_cy = P.prev_cy;
-        I.prev_cx = P.prev_cx;
+        prev_cy = P.prev_cy;
+        prev_cx = P.prev_cx;
     }
-    I.Gprev = F.gbuf[(F.pb + k) % 3];
+    // one pending layer (the previous colour), written back by every item
+    I.n_lay = prev_cy >= 0 ? 1 : 0;
+    I.write_back = 1;
+#pragma unroll
+    for (int j = 0; j < MH_LAYERS; ++j) {
+        I.lay_cy[j] = prev_cy;
+        I.lay_cx[j] = prev_cx;
+        I.lay_G[j] = F.gbuf[(F.pb + k) % 3];
+    }
     I.Gcur = F.gbuf[(F.pb + k + 1) % 3];
-    const bool idle = !I.real && I.prev_cy < 0;  // nothing pending, nothing to do
+    const bool idle = !I.real && I.n_lay == 0;  // nothing pending, nothing to do
     bool ok = true;
-    mh_ws_preds(P, I);
-    if (!idle) mh_ws_table(P, S, I, NT);
+    mh_ws_preds<1>(P, I);
+    if (!idle) mh_ws_table<1>(P, S, I, NT);
     if (k > 0 && tid < 5) {
         // lanes 0..3: the predecessors (lattice points of colour k-1 whose windows
         // intersect this one inside the cube); lane 4: colour k-2 complete
         if (tid < 4) {
             const int wy = (tid >> 1) ? min(I.y + fhh, P.H - 1) : max(I.y - fhh, 0);
             const int wx = (tid & 1) ? min(I.x + fhw, P.W - 1) : max(I.x - fhw, 0);
-            const int sy = covering_lattice(wy, I.prev_cy, P.fh, fhh);
-            const int sx = covering_lattice(wx, I.prev_cx, P.fw, fhw);
-            const int iy = (sy - I.prev_cy) / P.fh + 1, ix = (sx - I.prev_cx) / P.fw + 1;
+            const int sy = covering_lattice(wy, prev_cy, P.fh, fhh);
+            const int sx = covering_lattice(wx, prev_cx, P.fw, fhw);
+            const int iy = (sy - prev_cy) / P.fh + 1, ix = (sx - prev_cx) / P.fw + 1;
             int li = -1;
             if (iy >= 0 && iy < F.LY && ix >= 0 && ix < F.LX)
                 li = F.lat[((long)(k - 1) * F.LY + iy) * F.LX + ix];
@@ -2303,11 +2376,11 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     // a timed-out wait skips the item (*F.err is set: the host reports it)
     if (__syncthreads_or(!ok)) return;
     if (!idle) {
-        double gv[MH_GP_MAX];
-        mh_ws_gp_load<true>(P, I, NT, gv);
-        mh_ws_gp_store(P, S, NT, gv);
+        MHGpRegs<1> gv;
+        mh_ws_gp_load<1, true>(P, I, NT, gv);
+        mh_ws_gp_store<1>(P, S, I, NT, gv);
         __syncthreads();
-        mh_ws_run<NS, UV, true, 1>(P, S, I, sweep, item);
+        mh_ws_run<NS, UV, true, 1, 1>(P, S, I, sweep, item);
     } else {
         mh_ws_zero_row<true>(P, I);
     }
@@ -2392,8 +2465,8 @@ __global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
     }
 }
 
-// Apply the pending updates of colour (prev_cy, prev_cx) to the whole residual
-// (before anything other than the next colour launch looks at it).
+// Apply the pending layers (oldest first) to the whole residual, before anything
+// other than the next colour launch looks at it.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
     const int S = NT / P.HL;
@@ -2402,16 +2475,22 @@ __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
     if (s >= S || vox >= (long)P.H * P.W) return;
     const int yy = (int)(vox / P.W), xx = (int)(vox - (long)yy * P.W);
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
-    const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
-    const int sx = covering_coord(xx, P.prev_cx, P.fw, fhw, P.W);
-    if (sy < 0 || sx < 0 || !P.mask[sy * P.W + sx]) return;
-    const double fp = P.fsf[(yy - sy + fhh) * P.fw + (xx - sx + fhw)];
-    const double2 gz = *reinterpret_cast<const double2 *>(
-        P.Gprev + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * P.Dp + 2 * zl);
     double2 e = *reinterpret_cast<const double2 *>(P.err + vox * P.Dp + 2 * zl);
-    e.x = fma(fp, gz.x, e.x);
-    e.y = fma(fp, gz.y, e.y);
-    *reinterpret_cast<double2 *>(P.err + vox * P.Dp + 2 * zl) = e;
+    bool touched = false;
+#pragma unroll
+    for (int j = 0; j < MH_LAYERS; ++j) {
+        if (j >= P.n_lay) continue;
+        const int sy = covering_coord(yy, P.lay_cy[j], P.fh, fhh, P.H);
+        const int sx = covering_coord(xx, P.lay_cx[j], P.fw, fhw, P.W);
+        if (sy < 0 || sx < 0 || !P.mask[sy * P.W + sx]) continue;
+        const double fp = P.fsf[(yy - sy + fhh) * P.fw + (xx - sx + fhw)];
+        const double2 gz = *reinterpret_cast<const double2 *>(
+            P.lay_G[j] + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * P.Dp + 2 * zl);
+        e.x = fma(fp, gz.x, e.x);
+        e.y = fma(fp, gz.y, e.y);
+        touched = true;
+    }
+    if (touched) *reinterpret_cast<double2 *>(P.err + vox * P.Dp + 2 * zl) = e;
 }
 
 }  // namespace d3d

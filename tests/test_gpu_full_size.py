@@ -99,16 +99,17 @@ def test_chain_reproducible_and_residual_consistent(problem):
 @pytest.mark.parametrize("uniform", [False, True])
 def test_sweep_dataflow_kernel_equals_per_colour_launches(monkeypatch, problem, uniform):
     """k_mh_flow (one launch per sweep; windows wait for the flags of the <= 4
-    windows of the previous colour they intersect, hand-off through agent-scope
-    release/acquire across the XCDs) against k_mh_ws (a kernel boundary after
-    every colour): 270 000 updates, chains, residuals and delta maps
-    bit-identical.  A stale line anywhere in a window
+    windows of the previous colour they intersect, sc1 hand-off across the XCDs)
+    against k_mh_ws (a kernel boundary after every colour) with the residual
+    written back every colour, every second and every third one: 270 000
+    updates, chains, residuals and delta maps bit-identical.  A stale line anywhere in a window
     would show up here."""
     var = problem["var"] if uniform else problem["var"] * (
         0.75 + 0.5 * np.random.default_rng(5).random(problem["var"].shape))
     outs = []
-    for env in ({"D3D_MH_FLOW": "1"}, {"D3D_MH_FLOW": "0"}):
-        for k in ("D3D_MH_FLOW", "D3D_MH_DEFER"):
+    for env in ({"D3D_MH_FLOW": "1"}, {"D3D_MH_LAYERS": "1"}, {"D3D_MH_LAYERS": "2"},
+                {"D3D_MH_LAYERS": "3"}):
+        for k in ("D3D_MH_FLOW", "D3D_MH_DEFER", "D3D_MH_LAYERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
