@@ -653,13 +653,15 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // (the uniform-variance variant also gains from the deeper queue at full size:
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
+    // (with several layers most launches only read: two positions in flight pay at
+    // full size, 43.3 -> 42.6 us per colour)
     if (c->mh_layers >= 3) {
         if (small) return launch_mh_ws_um<UV, 4, 3>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 1, 3>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 3>(c, P, grid, sweep);
     }
     if (c->mh_layers == 2) {
         if (small) return launch_mh_ws_um<UV, 4, 2>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 1, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 2>(c, P, grid, sweep);
     }
     if (small) return launch_mh_ws_um<UV, 4, 1>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1>(c, P, grid, sweep);
