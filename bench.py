@@ -260,7 +260,12 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic("k_mh_ws<256, false,", args.workload),
                 "bytes_per_launch": bytes_per_sweep // ncol,
-                "avg_launch_us": round(avg_launch_us, 2), "launches": launches}
+                "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
+                # `achieved` prices the 24 B per window voxel of SURVEY 8(d) (read residual,
+                # read 1/var, write residual); the kernel itself stores the residual only
+                # every `residual_written_every` colours and applies the pending updates
+                # in registers in between, which is why `traffic` is lower
+                "residual_written_every": eng.mh_layers()}
 
     # ---- separable convolution roofline (north_star's second target) ---------
     # cube in -> cube out, device resident.  (a) in the reference's own (D,H,W)

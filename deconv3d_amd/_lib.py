@@ -27,7 +27,7 @@ SYMBOLS = [
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
     "d3d_convolve_slots", "d3d_stage_upload", "d3d_stage_convolve", "d3d_stage_download",
     "d3d_mh_config", "d3d_window_stats",
-    "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform",
+    "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform", "d3d_mh_layers",
     "d3d_colour_count",
     "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
@@ -97,6 +97,7 @@ def load():
                                   dbl_p, C.POINTER(C.c_int64)]
     lib.d3d_get_dlog.argtypes = [ctx_p, dbl_p]
     lib.d3d_variance_is_uniform.argtypes = [ctx_p, C.POINTER(C.c_int)]
+    lib.d3d_mh_layers.argtypes = [ctx_p, C.POINTER(C.c_int)]
     lib.d3d_mh_colour_lines.argtypes = [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_int), dbl_p,
                                         dbl_p, C.c_int, dbl_p]
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
@@ -340,6 +341,11 @@ class Engine(object):
         flag = C.c_int(0)
         _check(self._lib.d3d_variance_is_uniform(self._ctx, C.byref(flag)))
         return bool(flag.value)
+
+    def mh_layers(self):
+        n = C.c_int(0)
+        _check(self._lib.d3d_mh_layers(self._ctx, C.byref(n)))
+        return n.value
 
     def colour_count(self, colour):
         n = C.c_int(0)

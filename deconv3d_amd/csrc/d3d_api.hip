@@ -1610,6 +1610,13 @@ int d3d_x_stamps_read(d3d_ctx *c, int launch, int n, unsigned long long *out) {
 }
 #endif
 
+int d3d_mh_layers(d3d_ctx *c, int *out) {
+    NEED(c && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_data, D3D_ERR_STATE, "data not set");
+    *out = (c->mh_defer && !c->tiled) ? c->mh_layers : 0;
+    return D3D_OK;
+}
+
 int d3d_variance_is_uniform(d3d_ctx *c, int *out) {
     NEED(c && out, D3D_ERR_INVALID, "NULL argument");
     NEED(c->have_data, D3D_ERR_STATE, "data not set");

@@ -175,6 +175,13 @@ int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
  * only (16 instead of 24 bytes per window voxel; results are bit-identical to
  * the general kernel).  Environment D3D_UNIFORM_IVAR=0 turns the variant off. */
 int d3d_variance_is_uniform(d3d_ctx *ctx, int *out);
+/* *out = number of colours whose residual updates d3d_mh_sweeps keeps pending as
+ * (colour, coefficient rows) layers before it writes the residual back: 2 by
+ * default (the residual is stored every second colour: writing it costs about
+ * twice what reading it does on MI355X), 1 for cubes whose colour launches do not
+ * fill the chip, 0 when updates are written at once (tiled contexts).  The chain
+ * is bit-identical for every value.  Environment D3D_MH_LAYERS=1|2|3. */
+int d3d_mh_layers(d3d_ctx *ctx, int *out);
 
 /* ---- spatial tiling (one chain over several GPUs) --------- */
 /* The reference has no counterpart (single process).  A tile ctx holds a
