@@ -383,8 +383,8 @@ def main():
                 eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
             g_ms = eng.timer_stop() / max(args.conv_iters, 1)
             out["roofline_conv_gaussian"] = conv_entry(
-                g_ms, "k_spectral_dense + k_spatial_sep (Gaussian 11x11 FSF = outer product)",
-                "k_spatial_sep")
+                g_ms, "k_spatial_sep_lsf (Gaussian 11x11 FSF = outer product; LSF in the same pass)",
+                "k_spatial_sep_lsf")
             out["roofline_conv_gaussian"]["fp64_tflops"] = round(
                 2.0 * (fh + fw + ntaps_lsf) * D * H * W / (g_ms * 1e-3) / 1e12, 2)
             out["roofline_conv_gaussian"].pop("fp64_frac", None)

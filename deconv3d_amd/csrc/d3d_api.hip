@@ -129,6 +129,7 @@ struct d3d_ctx {
     double *extbuf = nullptr;        // external-lines staging: [cap][6 + 2D] doubles
     size_t ext_cap = 0;              // spaxels per d3d_mh_colour_lines call it can hold
     bool fsf_sep = false;         // fsf == u v^T to rounding (k_spatial_sep); D3D_SPATIAL_SEP=0 disables
+    bool sep_fuse = true;         // LSF in the same pass (k_spatial_sep_lsf); D3D_SEP_FUSE=0 disables
     double *sep_uv = nullptr;     // [fh + fw] on the device
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
@@ -328,8 +329,28 @@ int launch_march_stamped(d3d_ctx *c, d3d::SpatialArgs A, const double *in, doubl
 
 #endif  // D3D_EXPERIMENTS
 
+// One pass for LSF x outer-product FSF (A.lsf_dense set; a strip within a wavefront).
+template <int NT, int FS>
+int launch_sep_lsf(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    constexpr int TX = (FS >= 9 ? 3 : 4);
+    const int S = NT / c->HL;
+    const int HY = c->march_hy;
+    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
+    const unsigned grid = (unsigned)((items + S - 1) / S);
+    const size_t lds = (size_t)S * TX * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double);
+    if ((c->HL % 64) == 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep_lsf<NT, FS, TX, true>), dim3(grid),
+                           dim3(NT), lds, c->stream, A, in, out, HY);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep_lsf<NT, FS, TX, false>), dim3(grid),
+                           dim3(NT), lds, c->stream, A, in, out, HY);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <int NT, int FS>
 int launch_sep(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
+    if (A.lsf_dense) return launch_sep_lsf<NT, FS>(c, A, in, out);
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const int S = NT / c->HL;
     const int HY = c->march_hy;
@@ -347,7 +368,7 @@ int launch_sep(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *
 
 template <int NT, int FS, bool FUSE>
 int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    if (!FUSE && A.sep_uv) return launch_sep<NT, FS>(c, A, in, out);
+    if (A.sep_uv && (!FUSE || c->sep_fuse)) return launch_sep<NT, FS>(c, A, in, out);
     constexpr int TX = (FS >= 9 ? 3 : 4);
     const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
     const bool symx = c->march_mode >= 2 && c->fsf_symx;
@@ -436,7 +457,7 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     A.fsf = c->fsf;
     A.data = data;
     A.lsf_dense = nullptr;
-    A.sep_uv = (c->fsf_sep && !fuse_lsf) ? c->sep_uv : nullptr;
+    A.sep_uv = (c->fsf_sep && (!fuse_lsf || c->sep_fuse)) ? c->sep_uv : nullptr;
     A.xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
     A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
     A.dbg = nullptr;
@@ -447,6 +468,12 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     if (c->march_mode > 0 && c->fh == c->fw) {
         bool done = false;
         int rc;
+        if (fuse_lsf && A.sep_uv && c->sep_fuse) {  // LSF x outer-product FSF in one pass
+            A.lsf_dense = c->lsf_dense;
+            rc = launch_march_any<NT, false>(c, A, in, out, &done);
+            if (done) return rc;
+            A.lsf_dense = nullptr;
+        }
 #ifdef D3D_EXPERIMENTS
         if (fuse_lsf) {
             A.lsf_dense = c->lsf_dense;
@@ -481,10 +508,15 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
 
 // True when the spatial pass can apply the LSF itself (fused epilogue).
 bool can_fuse_lsf(const d3d_ctx *c) {
+    if (!c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
+    const bool sep = c->fsf_sep && c->sep_fuse;  // k_spatial_sep_lsf
 #ifndef D3D_EXPERIMENTS
-    return false;  // the fused epilogue is an experiment (slower than the streaming LSF pass)
+    // the fused epilogue of the 2-D march kernel is an experiment (register spills:
+    // slower than the streaming LSF pass)
+    if (!sep) return false;
+#else
+    if (!sep && !c->fuse_lsf) return false;
 #endif
-    if (!c->fuse_lsf || !c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;
         default: return false;
@@ -1119,6 +1151,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
                     }
         }
         if (const char *e = getenv("D3D_SPATIAL_SEP")) sep = sep && atoi(e) != 0;
+        if (const char *e = getenv("D3D_SEP_FUSE")) c->sep_fuse = atoi(e) != 0;
         c->fsf_sep = sep;
         if (sep)
             HIP_TRY(hipMemcpyAsync(c->sep_uv, uv.data(), uv.size() * sizeof(double),

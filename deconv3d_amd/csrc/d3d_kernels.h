@@ -791,6 +791,143 @@ __global__ __launch_bounds__(NT, 2) void k_spatial_sep(SpatialArgs A, const doub
     }
 }
 
+// LSF x FSF in ONE pass for an outer-product FSF: k_spatial_sep whose finished
+// output row goes through the dense LSF before it is stored (FSF and LSF act on
+// different axes and commute).  The strip's Dp-channel spectrum passes through a
+// wave-private LDS buffer with a circular halo of LSF_RL channels and each lane
+// applies the taps to its aligned window.  Needs a power-of-two depth whose
+// spectrum fits a wavefront and taps within +-LSF_RL (c->lsf_fusable).
+// The row loop is NOT unrolled and the ring shifts by register moves: the
+// rotating-ring form replicates the epilogue FS times and the compiler then
+// overlaps the next row's 13 loads with it -- 256 VGPRs and 273 spills (115 us).
+template <int NT, int FS, int TX, bool UNI>
+__global__ __launch_bounds__(NT, 2) void k_spatial_sep_lsf(SpatialArgs A, const double *__restrict__ in,
+                                                           double *__restrict__ out, int HY) {
+    constexpr int FHH = (FS - 1) / 2;
+    constexpr int NR = TX + FS - 1;
+    constexpr int RL = LSF_RL;
+    __shared__ double s_uv[2 * FS];
+    extern __shared__ double s_spec[];  // [strip][TX][Dp + 2*RL]
+    for (int i = threadIdx.x; i < 2 * FS; i += NT) s_uv[i] = A.sep_uv[i];
+    __syncthreads();
+
+    const int S = NT / A.HL;
+    int s = threadIdx.x / A.HL;
+    const int zl = threadIdx.x - s * A.HL;
+    if constexpr (UNI) s = __builtin_amdgcn_readfirstlane(s);
+    const int nxs = (A.W + TX - 1) / TX;
+    const int nys = (A.H + HY - 1) / HY;
+    int blk = blockIdx.x;
+    if (A.xcd_remap) {
+        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+    }
+    const long item = (long)blk * S + s;
+    if (s >= S || item >= (long)nxs * nys) return;
+    const int ys = (int)(item / nxs);
+    const int x0 = (int)(item - (long)ys * nxs) * TX;
+    const int y0 = ys * HY;
+    const int yend = min(y0 + HY, A.H);
+    const long rowstride = (long)A.W * A.Dp;
+    const bool xin = (x0 - FHH >= 0) && (x0 + TX - 1 + FHH < A.W);
+    const int N = A.Dp;
+    double *buf = s_spec + (size_t)s * TX * (N + 2 * RL);
+
+    double2 ring[FS][TX];
+#pragma unroll
+    for (int k = 0; k < FS; ++k)
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
+
+    const int nsteps = (yend - y0) + 2 * FHH;
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        const int r = y0 - FHH + step;
+        if (r >= 0 && r < A.H) {
+            const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
+            double2 row[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int xx = x0 - FHH + i;
+                row[i] = (xin || (xx >= 0 && xx < A.W))
+                             ? *reinterpret_cast<const double2 *>(base + (long)i * A.Dp)
+                             : make_double2(0.0, 0.0);
+            }
+            double2 X[TX];
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const double v0 = s_uv[FS];
+                X[t].x = v0 * row[t + FS - 1].x;
+                X[t].y = v0 * row[t + FS - 1].y;
+            }
+#pragma unroll
+            for (int m = 1; m < FS; ++m) {
+                const double vm = s_uv[FS + m];
+#pragma unroll
+                for (int t = 0; t < TX; ++t) {
+                    X[t].x = fma(vm, row[t + FS - 1 - m].x, X[t].x);
+                    X[t].y = fma(vm, row[t + FS - 1 - m].y, X[t].y);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FS; ++k) {
+                const int oy = r - FHH + k;
+                if (oy >= y0 && oy < yend) {
+                    const double uk = s_uv[k];
+#pragma unroll
+                    for (int t = 0; t < TX; ++t) {
+                        ring[k][t].x = fma(uk, X[t].x, ring[k][t].x);
+                        ring[k][t].y = fma(uk, X[t].y, ring[k][t].y);
+                    }
+                }
+            }
+        }
+        const int oy0 = r - FHH;  // slot 0 has received its last tap row
+        if (oy0 >= y0 && oy0 < yend) {
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                double *bt = buf + t * (N + 2 * RL);
+                const double2 v = ring[0][t];
+                *reinterpret_cast<double2 *>(bt + RL + 2 * zl) = v;
+                if (2 * zl < RL) *reinterpret_cast<double2 *>(bt + N + RL + 2 * zl) = v;
+                if (2 * zl >= N - RL) *reinterpret_cast<double2 *>(bt + RL + 2 * zl - N) = v;
+            }
+            __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS is in order per wave
+#pragma unroll
+            for (int t = 0; t < TX; ++t) {
+                const int xo = x0 + t;
+                const double *bt = buf + t * (N + 2 * RL) + 2 * zl;
+                //   acc.x = sum_j wl[j] w[j],  acc.y = sum_j wl[j] w[j+1]
+                double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+                for (int j = 0; j < RL + 1; ++j) {
+                    const double2 p = *reinterpret_cast<const double2 *>(bt + 2 * j);
+                    if (2 * j <= 2 * RL) acc.x = fma(A.lsf_dense[2 * j], p.x, acc.x);
+                    if (2 * j + 1 <= 2 * RL) acc.x = fma(A.lsf_dense[2 * j + 1], p.y, acc.x);
+                    if (2 * j - 1 >= 0) acc.y = fma(A.lsf_dense[2 * j - 1], p.x, acc.y);
+                    if (2 * j <= 2 * RL) acc.y = fma(A.lsf_dense[2 * j], p.y, acc.y);
+                }
+                if (xo < A.W) {
+                    const long o = (long)oy0 * rowstride + (long)xo * A.Dp + 2 * zl;
+                    if (A.data) {
+                        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+                        acc.x = d.x - acc.x;
+                        acc.y = d.y - acc.y;
+                    }
+                    *reinterpret_cast<double2 *>(out + o) = acc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int k = 0; k < FS - 1; ++k)
+#pragma unroll
+            for (int t = 0; t < TX; ++t) ring[k][t] = ring[k + 1][t];
+#pragma unroll
+        for (int t = 0; t < TX; ++t) ring[FS - 1][t] = make_double2(0.0, 0.0);
+    }
+}
+
 // Software-pipelined column march for FSFs that are mirror-symmetric in x AND
 // y, one strip per wavefront (HL multiple of 64).  Same ring / symmetry algebra
 // as k_spatial_march<SYMX, SYMY>; in addition the NEXT input row is loaded while

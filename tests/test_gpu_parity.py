@@ -88,18 +88,28 @@ def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
     lsf = O.gaussian_lsf_vector(D, 0.8)
     cube = rng.normal(size=shape)
     outs = []
-    for knob in ("1", "0"):
-        monkeypatch.setenv("D3D_SPATIAL_SEP", knob)
+    # separable with the LSF in the same pass (power-of-two depths), separable
+    # after the streaming LSF pass, 2-D kernel; each also through the forward
+    # model, whose lines are already LSF-convolved (never the one-pass kernel)
+    for sep, fuse in (("1", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("D3D_SPATIAL_SEP", sep)
+        monkeypatch.setenv("D3D_SEP_FUSE", fuse)
         with _lib.Engine(shape, fsf.shape) as eng:
             eng.set_taps(fsf, lsf)
             eng.upload_slot(_lib.SLOT_TMP0, cube)
             eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
             outs.append(eng.download_slot(_lib.SLOT_SIM))
+            eng.set_data(cube, None, var_scalar=1.0)
+            eng.set_params(np.tile([1.0, D / 2.0, 1.5], (H, W, 1)))
+            outs.append(eng.forward())
     ref = O.convolve_cube(cube, fsf, lsf)
-    assert_cube_close(outs[0], ref, "separable pass vs oracle")
-    assert_cube_close(outs[1], ref, "2-D pass vs oracle")
-    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-13 * np.max(np.abs(ref))
-    assert not np.array_equal(outs[0], outs[1])      # two different summation orders did run
+    for k, what in ((0, "one pass"), (2, "separable"), (4, "2-D")):
+        assert_cube_close(outs[k], ref, what + " vs oracle")
+        assert np.max(np.abs(outs[k] - outs[4])) <= 1e-13 * np.max(np.abs(ref))
+        assert np.max(np.abs(outs[k + 1] - outs[5])) <= 1e-13 * np.max(np.abs(outs[5]))
+    assert not np.array_equal(outs[2], outs[4])      # two different summation orders did run
+    if D & (D - 1) == 0:
+        assert not np.array_equal(outs[0], outs[2])  # and the one-pass form too
 
 
 def test_spectral_pass_by_wavefront_shuffles_is_bit_identical(monkeypatch):
