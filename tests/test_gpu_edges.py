@@ -30,8 +30,8 @@ def small_problem(D, H, W, fsf, lsf, seed=0):
 
 @pytest.mark.parametrize("D", [100, 128, 200, 256, 300, 512, 1000, 1024])
 def test_deep_cubes_chain_matches_oracle(D):
-    """Depths that select every MH kernel: wave-specialised (D <= 256, 2 or 4
-    prepare waves), plain deferred (D > 256), 256/512/1024-thread blocks, and
+    """Depths that select every MH kernel: wave-specialised (D <= 256), plain
+    deferred (D > 256), 256/512/1024-thread blocks, and
     non-power-of-two depths with the partial-wrap LSF."""
     H, W = 5, 6
     fsf = O.gaussian_fsf_image(1.6)
