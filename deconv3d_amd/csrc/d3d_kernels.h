@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long
 // so ONE pass over the err and 1/var windows suffices, and the residual changes
 // by  err += f * G[z],  G = a E_old - r E_end                      (:508-515).
 //
-// Two write-back schemes, bit-identical in their results:
+// Write-back schemes, bit-identical in their results:
 //   k_mh        immediate: pass 2 re-reads (or keeps in registers) the err
 //               window and writes e + f G.  4 cube passes per colour.
 //   k_mh_defer  deferred: the update is NOT written; G goes to a small side
@@ -1454,6 +1454,11 @@ __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long
 //               voxel has exactly one pending spaxel): each voxel is read once
 //               and written once per colour -- the algorithmic 3 passes
 //               (read err, read 1/var, write err) and no second pass.
+//   k_mh_ws     deferred, wave-specialised, and with up to MH_LAYERS colours
+//               pending at once: the residual is written back only every M-th
+//               colour (the default path; see "Several pending layers").
+//   k_mh_flow   k_mh_ws's window code under per-window dependencies, one launch
+//               per sweep (opt-in).
 
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
