@@ -1652,7 +1652,7 @@ __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const 
 __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, const MHProposal &q,
                                           int sp, uint32_t sweep, int ch, int G, double EO,
                                           double EN, int first, int nw, bool caller,
-                                          double *Gz_out) {
+                                          double *Gz_out, const U2 *u_pre = nullptr) {
     const int Dp = P.Dp, D = P.D;
     double sums[7] = {0, 0, 0, 0, 0, 0, 0};
     const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
@@ -1661,7 +1661,7 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
     // drawn here, ahead of the barrier, they are off the critical tail
     U2 u_gibbs = {0.5, 0.5};
     if (caller) {
-        u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
+        u_gibbs = u_pre ? *u_pre : philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
         double Az = 0.0, Bz = 0.0, Cz = 0.0;
         if (ch < D) {
             for (int gg = 0; gg < G; ++gg) {
@@ -2222,6 +2222,11 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     const bool real = I.real != 0;
     const int sp = I.y * P.W + I.x;
     const bool streamer = tid < NS;
+    // the uniforms of the Gibbs draw, while the first loads of the window pass fly
+    U2 u_gibbs = {0.5, 0.5};
+    if (streamer && real && !P.ext_lines)
+        u_gibbs = philox_pair(P.seed, (uint32_t)((I.y + P.gy0) * P.Wg + (I.x + P.gx0)), sweep,
+                              BLK_GIBBS);
     if (streamer) {
         const int g = tid / HL, zl = tid - g * HL;
         if (g < G) {
@@ -2334,7 +2339,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
         }
     }
     double Gt;
-    if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt)) return;
+    if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs)) return;
     if (tid < Dp) {
         double *dst = I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * Dp + tid;
         if (COH)

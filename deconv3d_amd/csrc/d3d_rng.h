@@ -129,8 +129,15 @@ template <bool WAVE>
 __device__ inline double truncated_normal(double lo, double hi, double mu, double sigma, U2 u0,
                                           uint64_t seed, uint32_t spaxel, uint32_t sweep,
                                           uint32_t *blk) {
-    const double alpha = (lo - mu) / sigma;
-    const double beta = (hi - mu) / sigma;
+    double alpha, beta;
+    if (WAVE) {  // the two standardised bounds side by side, as the two CDFs below
+        const double x = (((__lane_id() & 32) ? hi : lo) - mu) / sigma;
+        alpha = __shfl(x, 0);
+        beta = __shfl(x, 32);
+    } else {
+        alpha = (lo - mu) / sigma;
+        beta = (hi - mu) / sigma;
+    }
     const double z = truncated_standard_normal<WAVE>(alpha, beta, u0, seed, spaxel, sweep, blk);
     return fmin(fmax(mu + sigma * z, lo), hi);
 }
