@@ -839,13 +839,15 @@ __global__ __launch_bounds__(NT, 2) void k_spatial_sep_lsf(SpatialArgs A, const 
 #pragma unroll
         for (int t = 0; t < TX; ++t) ring[k][t] = make_double2(0.0, 0.0);
 
+    // Software pipeline without extra registers: a row is reduced along x as soon
+    // as it has arrived (X), which frees its registers, and the NEXT row's loads
+    // are issued right then -- they fly while X feeds the ring, the finished row
+    // goes through the LSF and the ring shifts.
     const int nsteps = (yend - y0) + 2 * FHH;
-#pragma unroll 1
-    for (int step = 0; step < nsteps; ++step) {
-        const int r = y0 - FHH + step;
+    double2 row[NR];
+    auto load_row = [&](int r) {
         if (r >= 0 && r < A.H) {
             const double *base = in + (long)r * rowstride + (long)(x0 - FHH) * A.Dp + 2 * zl;
-            double2 row[NR];
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const int xx = x0 - FHH + i;
@@ -853,7 +855,15 @@ __global__ __launch_bounds__(NT, 2) void k_spatial_sep_lsf(SpatialArgs A, const 
                              ? *reinterpret_cast<const double2 *>(base + (long)i * A.Dp)
                              : make_double2(0.0, 0.0);
             }
-            double2 X[TX];
+        }
+    };
+    load_row(y0 - FHH);
+#pragma unroll 1
+    for (int step = 0; step < nsteps; ++step) {
+        const int r = y0 - FHH + step;
+        const bool live = r >= 0 && r < A.H;
+        double2 X[TX];
+        if (live) {
 #pragma unroll
             for (int t = 0; t < TX; ++t) {
                 const double v0 = s_uv[FS];
@@ -869,6 +879,11 @@ __global__ __launch_bounds__(NT, 2) void k_spatial_sep_lsf(SpatialArgs A, const 
                     X[t].y = fma(vm, row[t + FS - 1 - m].y, X[t].y);
                 }
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the next row's loads behind the x reduction
+        if (step + 1 < nsteps) load_row(r + 1);
+        __builtin_amdgcn_sched_barrier(0);  // ... and ahead of everything below
+        if (live) {
 #pragma unroll
             for (int k = 0; k < FS; ++k) {
                 const int oy = r - FHH + k;
