@@ -1409,6 +1409,28 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// Sum over the wavefront with DPP row shifts / broadcasts instead of LDS permutes
+// (no LDS round trip per step); the total lands in lane 63 and is broadcast.
+// Another association than wave_sum: use one or the other consistently.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, BANK_MASK, false);
+    // lanes that receive nothing (masked out or shifted in) add +0.0
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
+    v = dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
+    v = dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
+    v = dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+    v = dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    return __shfl(v, 63);
+}
+
 // out[sp] = 0.5 * sum_z err^2 * ivar (lib/run.py:423 per spectrum); one wave
 // per spaxel.
 __global__ __launch_bounds__(256) void k_chi2_map(const double *__restrict__ err,
@@ -1696,7 +1718,7 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
         sums[5] = EN * EN * Bz;
         sums[6] = EN * ulB;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) sums[k] = wave_sum(sums[k]);
+        for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp(sums[k]);
         const int wave = (threadIdx.x >> 6) - first;
         if ((threadIdx.x & 63) == 0) {
 #pragma unroll
