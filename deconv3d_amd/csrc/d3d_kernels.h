@@ -1421,14 +1421,15 @@ __device__ __forceinline__ double dpp_add(double v) {
     return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 
-__device__ __forceinline__ double wave_sum_dpp(double v) {
+// (the total is valid in lane 63 only)
+__device__ __forceinline__ double wave_sum_dpp63(double v) {
     v = dpp_add<0x111, 0xf, 0xf>(v);  // row_shr:1
     v = dpp_add<0x112, 0xf, 0xf>(v);  // row_shr:2
     v = dpp_add<0x114, 0xf, 0xe>(v);  // row_shr:4
     v = dpp_add<0x118, 0xf, 0xc>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
     v = dpp_add<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
     v = dpp_add<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-    return __shfl(v, 63);
+    return v;
 }
 
 // out[sp] = 0.5 * sum_z err^2 * ivar (lib/run.py:423 per spectrum); one wave
@@ -1718,9 +1719,9 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
         sums[5] = EN * EN * Bz;
         sums[6] = EN * ulB;
 #pragma unroll
-        for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp(sums[k]);
+        for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp63(sums[k]);
         const int wave = (threadIdx.x >> 6) - first;
-        if ((threadIdx.x & 63) == 0) {
+        if ((threadIdx.x & 63) == 63) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
         }
