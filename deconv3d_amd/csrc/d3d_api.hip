@@ -666,20 +666,21 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV, int U, int M>
+template <bool UV, int U, int M, int K>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M>), dim3(grid), dim3(NS + 64), lds,
-                       c->stream, P, sweep);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K>), dim3(grid), dim3(NS + 64),
+                       lds, c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // A launch that does not fill the chip (fewer workgroups than 2 per CU) is
 // latency-bound: four window positions in flight per wavefront instead of one.
-// The kernel for up to MH_LAYERS pending layers needs more LDS; with one layer
-// configured the lean variant runs.
+// The kernels for several pending layers need more LDS; with one layer
+// configured the lean variant runs.  The pending G rows of a layer (4*Dp values)
+// are staged in 2 registers per thread up to Dp = 160, in 4 beyond.
 template <bool UV>
 int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     // (the uniform-variance variant also gains from the deeper queue at full size:
@@ -687,16 +688,20 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
     // (with several layers most launches only read: two positions in flight pay at
     // full size, 43.3 -> 42.6 us per colour)
-    if (c->mh_layers >= 3) {
-        if (small) return launch_mh_ws_um<UV, 4, 3>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 2, 3>(c, P, grid, sweep);
+    if (c->mh_layers >= 3) {  // Dp <= 160
+        if (small) return launch_mh_ws_um<UV, 4, 3, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 3, 2>(c, P, grid, sweep);
     }
     if (c->mh_layers == 2) {
-        if (small) return launch_mh_ws_um<UV, 4, 2>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 2, 2>(c, P, grid, sweep);
+        if (c->Dp > 160) {
+            if (small) return launch_mh_ws_um<UV, 4, 2, 4>(c, P, grid, sweep);
+            return launch_mh_ws_um<UV, 2, 2, 4>(c, P, grid, sweep);
+        }
+        if (small) return launch_mh_ws_um<UV, 4, 2, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 2, 2>(c, P, grid, sweep);
     }
-    if (small) return launch_mh_ws_um<UV, 4, 1>(c, P, grid, sweep);
-    return launch_mh_ws_um<UV, 1, 1>(c, P, grid, sweep);
+    if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
+    return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
 }
 
 // One sweep in one launch (k_mh_flow).  P carries the pending colour of the
@@ -807,14 +812,16 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
-    // two registers per thread (Dp <= 160); the other MH kernels keep one layer
+    // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
+    // other MH kernels keep one layer
     if (const char *e = getenv("D3D_MH_LAYERS")) {
         c->mh_layers_cfg = atoi(e);
         c->mh_layers_forced = true;
     }
     if (c->mh_layers_cfg < 1) c->mh_layers_cfg = 1;
     if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
-    if (c->mh_defer != 1 || c->mh_flow || c->Dp > 160) c->mh_layers_cfg = 1;
+    if (c->Dp > 160 && c->mh_layers_cfg > 2) c->mh_layers_cfg = 2;
+    if (c->mh_defer != 1 || c->mh_flow || c->Dp > 256) c->mh_layers_cfg = 1;
     c->mh_layers = c->mh_layers_cfg;
 }
 

@@ -2172,23 +2172,24 @@ __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, 
 
 // The <= 4 pending G rows of every layer into LDS (S.gp[j][q][Dp]), in two halves
 // so that the loads can be in flight while the position table is computed
-// (4*Dp <= MH_GP_K * NT values per layer: checked by the launcher).
+// (4*Dp <= K * NT values per layer, K = 4 for one or two layers, 2 for three: the
+// launcher limits the layers accordingly).
 // COH (k_mh_flow): the rows were written in THIS launch by workgroups of any
 // XCD -- agent-scope (sc1) loads, never served from a stale L1 line.
-template <int M>
+template <int M, int K_>
 struct MHGpRegs {
-    static constexpr int K = (M == 1) ? 4 : 2;
-    double v[M][K];
+    static constexpr int K = K_;
+    double v[M][K_];
 };
 
-template <int M, bool COH>
+template <int M, int K, bool COH>
 __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
-                                              MHGpRegs<M> &R) {
+                                              MHGpRegs<M, K> &R) {
     const int Dp = P.Dp;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
 #pragma unroll
-        for (int k = 0; k < MHGpRegs<M>::K; ++k) {
+        for (int k = 0; k < K; ++k) {
             const int i = threadIdx.x + k * NT;
             R.v[j][k] = 0.0;
             if (j < I.n_lay && i < 4 * Dp) {
@@ -2210,13 +2211,13 @@ __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I
     }
 }
 
-template <int M>
+template <int M, int K>
 __device__ __forceinline__ void mh_ws_gp_store(const MHArgs &P, const MHShared &S, const MHWsItem &I,
-                                               int NT, const MHGpRegs<M> &R) {
+                                               int NT, const MHGpRegs<M, K> &R) {
 #pragma unroll
     for (int j = 0; j < M; ++j) {
 #pragma unroll
-        for (int k = 0; k < MHGpRegs<M>::K; ++k) {
+        for (int k = 0; k < K; ++k) {
             const int i = threadIdx.x + k * NT;
             if (j < I.n_lay && i < 4 * P.Dp) S.gp[(size_t)j * 4 * P.Dp + i] = R.v[j][k];
         }
@@ -2390,7 +2391,8 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     D3D_MH_STAMP(stamp_at, 4, 0);
 }
 
-template <int NS, bool UV, int U, int M>
+// K: registers per thread and layer that stage the pending G rows (4*Dp <= K*(NS+64))
+template <int NS, bool UV, int U, int M, int K>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
@@ -2408,10 +2410,10 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         return;
     }
     mh_ws_preds<M>(P, I);
-    MHGpRegs<M> gv;
-    mh_ws_gp_load<M, false>(P, I, NT, gv);  // in flight while the table is computed
+    MHGpRegs<M, K> gv;
+    mh_ws_gp_load<M, K, false>(P, I, NT, gv);  // in flight while the table is computed
     mh_ws_table<M>(P, S, I, NT);
-    mh_ws_gp_store<M>(P, S, I, NT, gv);
+    mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
     mh_ws_run<NS, UV, false, U, M>(P, S, I, sweep, blockIdx.x);
@@ -2561,9 +2563,9 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     // a timed-out wait skips the item (*F.err is set: the host reports it)
     if (__syncthreads_or(!ok)) return;
     if (!idle) {
-        MHGpRegs<1> gv;
-        mh_ws_gp_load<1, true>(P, I, NT, gv);
-        mh_ws_gp_store<1>(P, S, I, NT, gv);
+        MHGpRegs<1, 4> gv;
+        mh_ws_gp_load<1, 4, true>(P, I, NT, gv);
+        mh_ws_gp_store<1, 4>(P, S, I, NT, gv);
         __syncthreads();
         mh_ws_run<NS, UV, true, 1, 1>(P, S, I, sweep, item);
     } else {

@@ -179,7 +179,7 @@ int d3d_variance_is_uniform(d3d_ctx *ctx, int *out);
  * (colour, coefficient rows) layers before it writes the residual back: 2 by
  * default (the residual is stored every second colour: writing it costs about
  * twice what reading it does on MI355X), 1 for cubes whose colour launches do not
- * fill the chip, 0 when updates are written at once (tiled contexts).  The chain
+ * fill the chip or whose depth exceeds 256, 0 when updates are written at once (tiled contexts).  The chain
  * is bit-identical for every value.  Environment D3D_MH_LAYERS=1|2|3. */
 int d3d_mh_layers(d3d_ctx *ctx, int *out);
 
