@@ -1172,6 +1172,27 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
         const int v = atoi(e);
         if (v >= 1) c->zmajor_hy = v;
     }
+    // Rows per strip of the march kernels: a strip is one wavefront's worth of z
+    // (64 / HL strips per wavefront when the spectrum is shorter), the chip holds
+    // two such wavefronts per SIMD, and a strip costs HY + FS - 1 row steps.  Take
+    // the HY in 12..20 that needs the fewest rounds of wavefronts and, among those,
+    // the fewest steps (300 rows: 15 -> 20 strips of 25 steps, all resident at once;
+    // 16 -> 19 strips of 26 steps).
+    {
+        const int TX = (c->fw >= 9 ? 3 : 4);
+        const long slots = 2L * (c->flow_grid > 0 ? c->flow_grid : 1024);  // 8 wavefronts per CU
+        const int per_wave = c->HL >= 64 ? 1 : 64 / (c->HL > 0 ? c->HL : 1);
+        long best_cost = -1;
+        for (int hy = 12; hy <= 20; ++hy) {
+            const long strips = (long)((c->W + TX - 1) / TX) * ((c->H + hy - 1) / hy);
+            const long waves = (strips + per_wave - 1) / per_wave;
+            const long cost = ((waves + slots - 1) / slots) * (hy + c->fh - 1);
+            if (best_cost < 0 || cost <= best_cost) {
+                best_cost = cost;
+                c->march_hy = hy;
+            }
+        }
+    }
     if (const char *e = getenv("D3D_MARCH_HY")) {
         const int v = atoi(e);
         if (v >= 1) c->march_hy = v;
