@@ -19,16 +19,16 @@ LIB_PATH = os.environ.get("DECONV3D_HIP_LIB") or os.path.join(_HERE, "csrc", "li
 
 # every symbol include/deconv3d_hip.h declares (tests check the export list)
 SYMBOLS = [
-    "d3d_version", "d3d_last_error", "d3d_device_count",
+    "d3d_version", "d3d_source_hash", "d3d_last_error", "d3d_device_count",
     "d3d_ctx_create", "d3d_ctx_destroy", "d3d_ctx_set_stream", "d3d_sync",
     "d3d_timer_start", "d3d_timer_stop",
     "d3d_set_taps", "d3d_set_data", "d3d_set_params", "d3d_get_params",
-    "d3d_build_clean", "d3d_convolve", "d3d_forward", "d3d_residual",
+    "d3d_build_clean", "d3d_convolve", "d3d_forward", "d3d_simulate", "d3d_residual",
     "d3d_chi2_map", "d3d_upload_slot", "d3d_download_slot",
     "d3d_convolve_slots", "d3d_stage_upload", "d3d_stage_convolve", "d3d_stage_download",
-    "d3d_mh_config", "d3d_window_stats",
+    "d3d_mh_config", "d3d_mh_set_sweep_origin", "d3d_window_stats",
     "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform", "d3d_mh_layers",
-    "d3d_colour_count",
+    "d3d_colour_count", "d3d_rtnorm",
     "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
 
@@ -67,6 +67,7 @@ def load():
     dbl_p = C.POINTER(C.c_double)
     lib.d3d_version.restype = C.c_int
     lib.d3d_last_error.restype = C.c_char_p
+    lib.d3d_source_hash.restype = C.c_char_p
     lib.d3d_device_count.argtypes = [C.POINTER(C.c_int)]
     lib.d3d_ctx_create.argtypes = [C.POINTER(ctx_p)] + [C.c_int] * 6
     lib.d3d_ctx_destroy.argtypes = [ctx_p]
@@ -83,6 +84,8 @@ def load():
     lib.d3d_convolve.argtypes = [ctx_p, dbl_p, dbl_p]
     lib.d3d_forward.argtypes = [ctx_p, dbl_p]
     lib.d3d_residual.argtypes = [ctx_p, dbl_p]
+    lib.d3d_simulate.argtypes = [ctx_p, dbl_p, C.c_int, dbl_p]
+    lib.d3d_mh_set_sweep_origin.argtypes = [ctx_p, C.c_int64]
     lib.d3d_chi2_map.argtypes = [ctx_p, dbl_p, dbl_p]
     lib.d3d_upload_slot.argtypes = [ctx_p, C.c_int, dbl_p]
     lib.d3d_download_slot.argtypes = [ctx_p, C.c_int, dbl_p]
@@ -101,16 +104,22 @@ def load():
     lib.d3d_mh_colour_lines.argtypes = [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_int), dbl_p,
                                         dbl_p, C.c_int, dbl_p]
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
+    lib.d3d_rtnorm.argtypes = [ctx_p, C.c_long] + [C.c_double] * 4 + [C.c_uint64, C.c_int, dbl_p]
     lib.d3d_set_tile.argtypes = [ctx_p] + [C.c_int] * 7
     lib.d3d_mh_colour.argtypes = [ctx_p, C.c_int, C.c_int]
     lib.d3d_export_updates.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int), dbl_p]
     lib.d3d_apply_updates.argtypes = [ctx_p, C.c_int, dbl_p]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("d3d_version", "d3d_last_error"):
+        if name not in ("d3d_version", "d3d_last_error", "d3d_source_hash"):
             fn.restype = C.c_int
     _lib = lib
     return lib
+
+
+def source_hash():
+    """Hash of the sources the loaded binary was compiled from (csrc/Makefile)."""
+    return load().d3d_source_hash().decode("ascii", "replace")
 
 
 def device_count():
@@ -240,6 +249,14 @@ class Engine(object):
         _check(self._lib.d3d_forward(self._ctx, _dp(out) if fetch else None))
         return out
 
+    def simulate(self, params, convolved=True):
+        """simulate_clean / simulate_convolved of an explicit parameter map; the
+        chain state on the device is left alone."""
+        params = _c64(params, self.shape[1:] + (3,))
+        out = np.empty(self.shape, dtype=np.float64)
+        _check(self._lib.d3d_simulate(self._ctx, _dp(params), 1 if convolved else 0, _dp(out)))
+        return out
+
     def residual(self, fetch=True):
         out = np.empty(self.shape, dtype=np.float64) if fetch else None
         _check(self._lib.d3d_residual(self._ctx, _dp(out) if fetch else None))
@@ -285,6 +302,9 @@ class Engine(object):
                                        float(gibbs_apriori_variance),
                                        C.c_uint64(int(seed) & (2 ** 64 - 1)),
                                        int(refresh_every)))
+
+    def set_sweep_origin(self, origin):
+        _check(self._lib.d3d_mh_set_sweep_origin(self._ctx, int(origin)))
 
     def window_stats(self, y, x, p_new):
         p = _c64(p_new, (3,))
@@ -351,6 +371,15 @@ class Engine(object):
         n = C.c_int(0)
         _check(self._lib.d3d_colour_count(self._ctx, int(colour), C.byref(n)))
         return n.value
+
+    def rtnorm(self, lo, hi, mu=0., sigma=1., size=1, seed=12345, wave_mode=False):
+        """`size` draws of N(mu, sigma^2) truncated to [lo, hi] on the device:
+        drop-in for rtnorm(a, b, mu, sigma, size) of lib/rtnorm.py:21-92."""
+        out = np.empty(int(size), dtype=np.float64)
+        _check(self._lib.d3d_rtnorm(self._ctx, int(size), float(lo), float(hi), float(mu),
+                                    float(sigma), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                    1 if wave_mode else 0, _dp(out)))
+        return out
 
     # -- spatial tiling (deconv3d_amd/tiling.py) ----------------------------
     def set_tile(self, gy0, gx0, Wg, oy0, oy1, ox0, ox1):

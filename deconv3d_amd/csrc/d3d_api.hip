@@ -15,7 +15,10 @@
 #include "../../include/deconv3d_hip.h"
 #include "d3d_kernels.h"
 
-#define D3D_VERSION 100  // 0.1.0
+#define D3D_VERSION 200  // 0.2.0
+#ifndef D3D_SOURCE_HASH
+#define D3D_SOURCE_HASH "unknown"
+#endif
 
 namespace {
 
@@ -70,6 +73,7 @@ struct d3d_ctx {
     double *stage = nullptr;   // D*HW doubles, host-layout staging
     double *stage2 = nullptr;  // second staging (variance)
     double *params = nullptr;  // HW*3
+    double *params_alt = nullptr;  // HW*3: parameter map of d3d_simulate (not the chain state)
     uint8_t *mask = nullptr;   // HW
     double *fsf = nullptr;     // fh*fw
     int *lsf_shift = nullptr;
@@ -91,6 +95,7 @@ struct d3d_ctx {
     double ra = 0;
     uint64_t seed = 0;
     int refresh_every = 1000;
+    uint32_t sweep_origin = 0;  // Philox sweep index of sweep s is s + sweep_origin (resumed runs)
 
     int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
     int mh_defer = 1;             // deferred residual write-back (k_mh_defer)
@@ -205,22 +210,24 @@ int download_cube(d3d_ctx *c, const double *src, double *host) {
 }
 
 template <int NT>
-int launch_lines_nt(d3d_ctx *c, double *out, int convolved) {
+int launch_lines_nt(d3d_ctx *c, double *out, int convolved, const double *params) {
     d3d::SpectralArgs A = spectral_args(c);
     const int G = NT / c->HL;
     const unsigned grid = (unsigned)((c->HW + G - 1) / G);
     const size_t lds = (size_t)G * c->N * sizeof(double);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_lines<NT>), dim3(grid), dim3(NT), lds, c->stream, A,
-                       c->params, c->mask, out, convolved);
+                       params, c->mask, out, convolved);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int launch_lines(d3d_ctx *c, double *out, int convolved) {
+// params: (H,W,3) map on the device (NULL: the chain state c->params)
+int launch_lines(d3d_ctx *c, double *out, int convolved, const double *params = nullptr) {
+    if (!params) params = c->params;
     switch (pick_nt(c->HL)) {
-        case 256: return launch_lines_nt<256>(c, out, convolved);
-        case 512: return launch_lines_nt<512>(c, out, convolved);
-        default: return launch_lines_nt<1024>(c, out, convolved);
+        case 256: return launch_lines_nt<256>(c, out, convolved, params);
+        case 512: return launch_lines_nt<512>(c, out, convolved, params);
+        default: return launch_lines_nt<1024>(c, out, convolved, params);
     }
 }
 
@@ -945,6 +952,8 @@ extern "C" {
 
 int d3d_version(void) { return D3D_VERSION; }
 
+const char *d3d_source_hash(void) { return D3D_SOURCE_HASH; }
+
 const char *d3d_last_error(void) { return g_err.c_str(); }
 
 int d3d_device_count(int *count) {
@@ -1017,6 +1026,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->stage, (size_t)D * c->HW * sizeof(double)));
     CTX_TRY(hipMalloc(&c->stage2, (size_t)D * c->HW * sizeof(double)));
     CTX_TRY(hipMalloc(&c->params, (size_t)c->HW * 3 * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->params_alt, (size_t)c->HW * 3 * sizeof(double)));
     CTX_TRY(hipMalloc(&c->mask, (size_t)c->HW));
     CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->sep_uv, (size_t)(fh + fw) * sizeof(double)));
@@ -1074,7 +1084,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
-    void *ptrs[] = {c->stage, c->stage2, c->params, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
+    void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
@@ -1470,6 +1480,20 @@ int d3d_forward(d3d_ctx *c, double *out_sim) {
     return D3D_OK;
 }
 
+int d3d_simulate(d3d_ctx *c, const double *params, int convolved, double *out) {
+    NEED(c && params && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->have_taps || !convolved, D3D_ERR_STATE, "taps not set");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->params_alt, params, (size_t)c->HW * 3 * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], convolved ? 1 : 0, c->params_alt);
+    if (rc) return rc;
+    if (!convolved) return download_cube(c, c->slot[D3D_SLOT_TMP0], out);
+    rc = launch_spatial(c, c->slot[D3D_SLOT_TMP0], c->slot[D3D_SLOT_SIM], nullptr);
+    if (rc) return rc;
+    return download_cube(c, c->slot[D3D_SLOT_SIM], out);
+}
+
 int d3d_residual(d3d_ctx *c, double *out_err) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(c->have_taps && c->have_params && c->have_data, D3D_ERR_STATE,
@@ -1526,6 +1550,13 @@ int d3d_mh_config(d3d_ctx *c, const double min_b[3], const double max_b[3],
     return D3D_OK;
 }
 
+int d3d_mh_set_sweep_origin(d3d_ctx *c, int64_t origin) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(origin >= 0 && origin < (int64_t(1) << 31), D3D_ERR_INVALID, "sweep origin out of range");
+    c->sweep_origin = (uint32_t)origin;
+    return D3D_OK;
+}
+
 int d3d_window_stats(d3d_ctx *c, int y, int x, const double p_new[3], double out[5]) {
     NEED(c && p_new && out, D3D_ERR_INVALID, "NULL argument");
     NEED(c->have_taps && c->have_data && c->have_params, D3D_ERR_STATE,
@@ -1571,7 +1602,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                       c->flow_K > 0 && c->cube_elems * sizeof(double) < (size_t(1) << 31);
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
         if (flow) {
-            int rc = launch_mh_flow(c, (uint32_t)s);
+            int rc = launch_mh_flow(c, (uint32_t)s + c->sweep_origin);
             if (rc) return rc;
         }
         for (int col = 0; col < ncol && !flow; ++col) {
@@ -1591,14 +1622,14 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                 // the launch that finds mh_layers layers pending applies them for good
                 P.write_back = (c->lay_n >= c->mh_layers) ? 1 : 0;
                 const int g_cur = pend_free_buf(c);
-                int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s);
+                int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s + c->sweep_origin);
                 if (rc) return rc;
                 if (P.write_back) pend_clear(c);
                 // this launch's updates are the newest pending layer (local residues)
                 pend_push(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
                           ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw, g_cur);
             } else {
-                int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s);
+                int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s + c->sweep_origin);
                 if (rc) return rc;
             }
         }
@@ -1722,7 +1753,7 @@ int d3d_mh_colour(d3d_ctx *c, int colour, int sweep) {
     d3d::MHArgs P;
     fill_mh_args(c, P);
     P.spx = c->spx + c->colour_off[colour];
-    return launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep);
+    return launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep + c->sweep_origin);
 }
 
 int d3d_export_updates(d3d_ctx *c, int n, const int *spaxels, double *out) {
@@ -1815,6 +1846,29 @@ int d3d_mh_colour_lines(d3d_ctx *c, int sweep, int n, const int *spaxels, const 
     HIP_TRY(hipMemcpyAsync(out3, d_out, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost,
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma, uint64_t seed,
+               int wave_mode, double *out) {
+    NEED(c && out, D3D_ERR_INVALID, "NULL argument");
+    NEED(n >= 0 && n <= (1L << 24), D3D_ERR_INVALID, "sample count %ld out of range", n);
+    // lib/rtnorm.py:66-71
+    NEED(lo < hi, D3D_ERR_INVALID, "For a truncated normal, b must be greater than a.");
+    NEED(sigma > 0.0, D3D_ERR_INVALID, "sigma must be positive");
+    if (n == 0) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    double *buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, (size_t)n * sizeof(double)));
+    const long threads = wave_mode ? n * 64 : n;
+    hipLaunchKernelGGL(d3d::k_rtnorm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                       n, lo, hi, mu, sigma, seed, wave_mode, buf);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    HIP_TRY(e);
     return D3D_OK;
 }
 

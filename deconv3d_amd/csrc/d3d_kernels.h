@@ -2652,6 +2652,27 @@ __global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
     }
 }
 
+// n draws of TN(lo, hi; mu, sigma) with the sampler of the Gibbs step (d3d_rng.h;
+// distribution of lib/rtnorm.py:21-92).  Draw i uses the Philox stream of
+// (spaxel i, sweep 0).  wave_mode = 0: one thread per draw (scalar form);
+// wave_mode = 1: one wavefront per draw, every lane the same arguments -- the
+// form mh_finish runs (the two CDFs side by side in the wavefront's halves).
+__global__ __launch_bounds__(256) void k_rtnorm(long n, double lo, double hi, double mu,
+                                                 double sigma, uint64_t seed, int wave_mode,
+                                                 double *__restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long i = wave_mode ? t >> 6 : t;
+    if (i >= n) return;
+    uint32_t blk = BLK_GIBBS;
+    const U2 u0 = philox_pair(seed, (uint32_t)i, 0u, BLK_GIBBS);
+    double r;
+    if (wave_mode)
+        r = truncated_normal<true>(lo, hi, mu, sigma, u0, seed, (uint32_t)i, 0u, &blk);
+    else
+        r = truncated_normal<false>(lo, hi, mu, sigma, u0, seed, (uint32_t)i, 0u, &blk);
+    if (!wave_mode || (t & 63) == 0) out[i] = r;
+}
+
 // Apply the pending layers (oldest first) to the whole residual, before anything
 // other than the next colour launch looks at it.
 template <int NT>

@@ -75,8 +75,18 @@ _BITPIX = {-64: ">f8", -32: ">f4", 8: "u1", 16: ">i2", 32: ">i4", 64: ">i8"}
 def _parse_card_value(raw):
     raw = raw.split("/")[0].strip() if not raw.strip().startswith("'") else raw.strip()
     if raw.startswith("'"):
-        end = raw.find("'", 1)
-        return raw[1:end].strip()
+        # a quote inside a FITS string is doubled; the string ends at the first single one
+        out, i = [], 1
+        while i < len(raw):
+            if raw[i] == "'":
+                if i + 1 < len(raw) and raw[i + 1] == "'":
+                    out.append("'")
+                    i += 2
+                    continue
+                break
+            out.append(raw[i])
+            i += 1
+        return "".join(out).rstrip()
     if raw in ("T", "F"):
         return raw == "T"
     try:
@@ -122,6 +132,10 @@ def read_fits(path):
 
 
 def _card(key, value):
+    """One 80-character header card, or None for a value FITS cannot hold
+    (NaN / infinity: the standard has no representation for them)."""
+    if isinstance(value, (float, np.floating)) and not np.isfinite(value):
+        return None
     if isinstance(value, bool):
         v = "T" if value else "F"
         body = "%-8s= %20s" % (key, v)
@@ -130,7 +144,11 @@ def _card(key, value):
     elif isinstance(value, (float, np.floating)):
         body = "%-8s= %20s" % (key, repr(float(value)).upper().replace("E+", "E"))
     else:
-        body = "%-8s= %-20s" % (key, "'%-8s'" % str(value))
+        # quotes doubled, text cut so that the closing quote stays inside the card
+        text = str(value).replace("'", "''")[:68]
+        if text.endswith("'") and (len(text) - len(text.rstrip("'"))) % 2:
+            text = text[:-1]          # do not split a doubled quote
+        body = "%-8s= %-20s" % (key, "'%-8s'" % text)
     return body[:80].ljust(80)
 
 
@@ -146,7 +164,9 @@ def write_fits(path, data, header=None, clobber=False):
     for key, value in (header or {}).items():
         if key in skip or key.startswith("NAXIS"):
             continue
-        cards.append(_card(key, value))
+        card = _card(key, value)
+        if card is not None:
+            cards.append(card)
     cards.append("END".ljust(80))
     head = "".join(cards)
     head += " " * ((-len(head)) % 2880)

@@ -34,6 +34,8 @@ class HostModelChain(object):
         self.amp = np.asarray(jump_amp, float)
         self.mask = run.mask
         self.refresh_every = int(refresh_every)
+        self.seed = int(seed)
+        self.sweep_origin = 0
         self.rng = np.random.Generator(np.random.Philox(int(seed)))
         fh, fw = run.fsf.shape
         self.colours = []
@@ -52,6 +54,13 @@ class HostModelChain(object):
                 if self.mask[y, x] == 1:
                     self.unit[y, x] = self.unit_line(self.params[y, x])
         self.refresh()
+
+    def set_sweep_origin(self, origin):
+        """Resumed run: the device draws of sweep s use the streams of sweep
+        s + origin and the host proposals a generator keyed by (seed, origin)."""
+        self.sweep_origin = int(origin)
+        self.rng = np.random.Generator(np.random.Philox(key=[self.seed & (2 ** 64 - 1),
+                                                             self.sweep_origin]))
 
     # -- model evaluation ---------------------------------------------------
     def unit_line(self, p):
@@ -106,7 +115,7 @@ class HostModelChain(object):
                 in3[i, 1] = 1.0 if oob else 0.0
                 p_new_all[i] = p_new
             in3[:, 2] = np.log(1.0 - self.rng.random(n))                      # log U, U in (0,1]
-            out = self.eng.mh_colour_lines(s, ys * self.W + xs, in3, lines,
+            out = self.eng.mh_colour_lines(s + self.sweep_origin, ys * self.W + xs, in3, lines,
                                            gibbs=self.g is not None)
             for i in range(n):
                 y, x = int(ys[i]), int(xs[i])

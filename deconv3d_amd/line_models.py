@@ -53,9 +53,11 @@ class SingleGaussianLineModel(LineModel):
     def max_boundaries(self, runner):
         # lib/line_models.py:79-90: the FSF is normalised, so the amplitude
         # ceiling is max(data)/max(fsf); centre in [0, D-1], width in [0, D].
+        # NaN voxels (masked spectra, lib/run.py:157-162) are ignored: the
+        # reference's np.amax would make every bound NaN.
         data = runner.cube.data
         fsf_max = np.amax(runner.fsf)
-        a_max = np.amax(data)
+        a_max = np.nanmax(data)
         if fsf_max > 0:
             a_max = a_max / fsf_max
         return [a_max, data.shape[0] - 1, data.shape[0]]

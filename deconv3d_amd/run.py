@@ -60,8 +60,11 @@ class Run:
     ``initial_parameters``, ``jump_amplitude``, ``gibbs_apriori_variance``,
     ``max_iterations``, ``keep_one_in``, ``write_every``,
     ``min_acceptance_rate``; plus ``seed``, ``device``, ``refresh_every``,
-    ``sweeps_per_call`` and ``checkpoint`` (file prefix written every
-    ``write_every`` iterations).
+    ``sweeps_per_call``, ``checkpoint`` (file prefix written every
+    ``write_every`` iterations) and ``resume_state`` (the ``<prefix>_state.npz``
+    of a checkpoint: the sweep numbering, the accepted count and hence the
+    random-number streams continue where the checkpointed run stopped; pass the
+    checkpoint's ``<prefix>_parameters.npy`` as ``initial_parameters``).
     """
 
     def __init__(
@@ -83,6 +86,7 @@ class Run:
         refresh_every=1000,
         sweeps_per_call=None,
         checkpoint=None,
+        resume_state=None,
     ):
         # lib/run.py:112-114
         assert keep_one_in > 0, "keep_one_in= MUST be a positive integer"
@@ -173,6 +177,9 @@ class Run:
         names = self.model.parameters()
         self.logger.info("Min boundaries : %s" % dict(zip(names, min_boundaries)))
         self.logger.info("Max boundaries : %s" % dict(zip(names, max_boundaries)))
+        if not (np.isfinite(min_boundaries).all() and np.isfinite(max_boundaries).all()):
+            raise ValueError("Boundaries are not finite: min %s, max %s (NaN or infinite data?)"
+                             % (min_boundaries, max_boundaries))
         if (min_boundaries > max_boundaries).any():
             raise ValueError("Boundaries are inconsistent: min > max.")
         parameters_count = len(names)
@@ -238,6 +245,21 @@ class Run:
             self.engine.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
                                   gibbs_apriori_variance, seed=self.seed,
                                   refresh_every=refresh_every)
+        # a resumed run continues the checkpointed run's sweep numbering: sweep s of
+        # this segment draws the random numbers of sweep s + origin
+        self.sweep_origin = 0
+        resumed_accepted = None
+        if resume_state is not None:
+            state = np.load(resume_state) if isinstance(resume_state, str) else resume_state
+            if int(state["seed"]) != self.seed:
+                self.logger.warning("resume_state was written with seed %d, this run uses %d"
+                                    % (int(state["seed"]), self.seed))
+            self.sweep_origin = int(state["sweep_origin"]) + int(state["iteration"]) - 1
+            resumed_accepted = (int(state["accepted_count"]), int(state["iteration"]))
+            if host_chain is None:
+                self.engine.set_sweep_origin(self.sweep_origin)
+            else:
+                host_chain.set_sweep_origin(self.sweep_origin)
         self.logger.info("Iteration #1")
         if host_chain is None:
             self.engine.residual(fetch=False)          # lib/run.py:317-334
@@ -246,10 +268,13 @@ class Run:
         cur_iteration = 1
         cur_acceptance_rate = 0.
         accepted_count = spaxels_count             # first iteration counts as accepted
-        # the reference re-evaluates the stopping rule every sweep; sweeps are
-        # batched per device call here (at most up to the next saved sweep)
+        self._resumed_from = resumed_accepted      # (accepted, iterations) of earlier segments
+        # the reference re-evaluates the stopping rule (and logs) every sweep
+        # (lib/run.py:344-364): one sweep per device call whenever the rule is
+        # armed, so that the run stops exactly where the reference would; with
+        # min_acceptance_rate <= 0 sweeps are batched up to the next saved one
         if sweeps_per_call is None:
-            sweeps_per_call = max(1, min(int(keep_one_in), 64))
+            sweeps_per_call = 1 if min_acceptance_rate > 0 else max(1, min(int(keep_one_in), 64))
         if host_chain is not None:
             sweeps_per_call = 1
         self.iterations_done = 1
@@ -307,7 +332,11 @@ class Run:
 
     def _write_checkpoint(self, name, iteration, accepted_count):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
-        lib/run.py:790-797) and `<name>_chain.npy` (slots written so far)."""
+        lib/run.py:790-797), `<name>_chain.npy` (slots written so far) and
+        `<name>_state.npz` (iteration, seed, accepted count: `resume_state=`)."""
+        np.savez("%s_state.npz" % name, iteration=iteration, seed=self.seed,
+                 accepted_count=accepted_count, sweep_origin=self.sweep_origin,
+                 keep_one_in=self.keep_one_in)
         np.save("%s_parameters.npy" % name, self._host_chain.params if self._host_model
                 else self.engine.get_params())
         n_valid = (iteration - 1) // self.keep_one_in + 1
@@ -350,8 +379,7 @@ class Run:
         self._check_shape(shape)
         if self._host_model:
             return self._host_chain.clean_cube(np.asarray(parameters, dtype=np.float64))
-        self.engine.set_params(parameters)
-        return self.engine.build_clean()
+        return self.engine.simulate(parameters, convolved=False)
 
     def simulate_convolved(self, shape, parameters):
         """Cube of the LSF- and FSF-convolved lines (lib/run.py:623-652), by the
@@ -360,8 +388,7 @@ class Run:
         if self._host_model:
             return self.engine.convolve(
                 self._host_chain.clean_cube(np.asarray(parameters, dtype=np.float64)))
-        self.engine.set_params(parameters)
-        return self.engine.forward()
+        return self.engine.simulate(parameters, convolved=True)
 
     def contribution_of_spaxel(self, x, y, parameters, cube_width, cube_height, cube_depth,
                                fsf=None, lsf=None, lsf_fft=None):
@@ -372,22 +399,12 @@ class Run:
         are the run's own.
         """
         self._check_shape((cube_depth, cube_height, cube_width))
-        if self._host_model:
-            one = np.zeros((cube_depth, cube_height, cube_width))
-            one[:, y, x] = np.asarray(self.model.modelize(self, np.arange(cube_depth, dtype=float),
-                                                          parameters), dtype=np.float64)
-            return self.engine.convolve(one), lsf_fft
-        saved = self.engine.get_params()
-        only = np.zeros_like(saved)
-        only[..., 2] = 1.0
-        only[y, x] = parameters
-        single = np.zeros((cube_height, cube_width))
-        single[y, x] = 1
-        # a map with zero amplitude everywhere else contributes nothing
-        self.engine.set_params(only)
-        out = self.engine.forward()
-        self.engine.set_params(saved)
-        return out, lsf_fft
+        # the line on the host (one spectrum), LSF and FSF on the device; like the
+        # reference this ignores the mask, and the chain state is not touched
+        one = np.zeros((cube_depth, cube_height, cube_width))
+        one[:, y, x] = np.asarray(self.model.modelize(self, np.arange(cube_depth, dtype=float),
+                                                      parameters), dtype=np.float64)
+        return self.engine.convolve(one), lsf_fft
 
     def _check_shape(self, shape):
         if tuple(shape) != tuple(self.cube.data.shape):

@@ -59,6 +59,10 @@ typedef enum d3d_slot {
 
 /* library version: major*10000 + minor*100 + patch */
 int d3d_version(void);
+/* sha256 (first 16 hex digits) of the HIP/C++ sources this binary was compiled
+ * from (csrc/Makefile bakes it in); __graft_entry__.build() compares it with the
+ * sources in the tree and rebuilds on a mismatch. */
+const char *d3d_source_hash(void);
 /* thread-local message of the last failing call ("" if none) */
 const char *d3d_last_error(void);
 /* number of visible HIP devices (0 and D3D_OK when there is none) */
@@ -109,6 +113,11 @@ int d3d_convolve(d3d_ctx *ctx, const double *in_cube, double *out_cube);
  * (lib/run.py:623-652) == the sim of _compute_error_in_one_step
  * (lib/run.py:999-1029).  out_sim may be NULL (result stays in SLOT_SIM). */
 int d3d_forward(d3d_ctx *ctx, double *out_sim);
+/* Run.simulate_clean(shape, parameters) (convolved = 0, lib/run.py:597-621) and
+ * Run.simulate_convolved(shape, parameters) (convolved = 1, lib/run.py:623-652)
+ * for an EXPLICIT (H,W,3) parameter map: the chain state (d3d_set_params, the
+ * carried residual) is not touched.  Masked spaxels are zero. */
+int d3d_simulate(d3d_ctx *ctx, const double *params, int convolved, double *out_cube);
 /* err = data - forward(params), lib/run.py:334 and :525-534 / :999-1031.
  * Stored in SLOT_ERR; out_err may be NULL. */
 int d3d_residual(d3d_ctx *ctx, double *out_err);
@@ -139,6 +148,10 @@ int d3d_convolve_slots(d3d_ctx *ctx, int src_slot, int dst_slot);
 int d3d_mh_config(d3d_ctx *ctx, const double min_b[3], const double max_b[3],
                   const double jump_amp[3], double gibbs_apriori_variance,
                   uint64_t seed, int refresh_every);
+/* Resumed runs: sweep s draws the random numbers of sweep s + origin, so that a
+ * chain continued from a checkpoint (lib/run.py:790-797 -> initial_parameters)
+ * does not replay the random numbers of its first segment.  Default 0. */
+int d3d_mh_set_sweep_origin(d3d_ctx *ctx, int64_t origin);
 /* Parity probe: for a proposal p_new at spaxel (y,x) against the current
  * state, out = {ar_old, ar_new, ar_old-ar_new, sum ek^2/var, sum ek*ul/var}
  * (lib/run.py:400-426, 464-493).  Does not modify the state. */
@@ -167,6 +180,13 @@ int d3d_mh_sweeps(d3d_ctx *ctx, int n_sweeps, int first_sweep, int keep_one_in,
  * the residual update; out3[i*3 + 0..2] = {accepted, new amplitude, delta}. */
 int d3d_mh_colour_lines(d3d_ctx *ctx, int sweep, int n, const int *spaxels, const double *in3,
                         const double *lines, int gibbs, double *out3);
+/* rtnorm(a, b, mu, sigma, size), lib/rtnorm.py:21-92: n draws of the normal
+ * N(mu, sigma^2) truncated to [lo, hi], with the sampler the Gibbs step uses
+ * (own algorithm, same distribution; the reference's Chopin tables are GPL and
+ * are not reproduced).  Draw i uses the Philox stream (seed, i); wave_mode = 1
+ * runs the wavefront-cooperative form of the MH kernel (bit-identical draws). */
+int d3d_rtnorm(d3d_ctx *ctx, long n, double lo, double hi, double mu, double sigma,
+               uint64_t seed, int wave_mode, double *out);
 /* Last sweep's log acceptance ratios, (H,W). */
 int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
 /* *out = 1 when d3d_set_data found one constant variance and no NaN voxel -- the

@@ -24,7 +24,11 @@ Pinning status (see DESIGN.md "Oracle"):
       - the verbatim FFT pipeline of ``lib/convolution.py`` restated below and
         checked against the closed form used on the device,
       - the statistical known-answer of the reference's Matlab fixture
-        (tests/input/data14forAntoine.mat + Parametres_theoriques.mat).
+        (tests/input/data14forAntoine.mat + Parametres_theoriques.mat),
+      - the reference's saved convolved/deconvolved FITS pair, reproduced to
+        1e-15 through the older revision's 3-D FFT convolution restated below
+        (legacy_convolve_3d_same): a bit-level pin of padding / convolve_1d /
+        the Gaussian LSF vector at the non-power-of-two depth 30.
   * ``MUSELineSpreadFunction`` arithmetic lives in mpdaf (absent, unpinned
     version) -> parity unpinned for that class; treated as an input vector.
 
@@ -238,6 +242,66 @@ def convolve_cube(cube, fsf, lsf):
         for x in range(W):
             tmp[:, y, x] = spectral_convolve(cube[:, y, x], lsf)
     return spatial_convolve(tmp, fsf)
+
+
+# ---- the OLDER revision's convolution (lib/convolution.py:13-86, commented out
+# in v0.3.0): a 3-D circular FFT convolution of the cube, padded to powers of two
+# on every axis, with a 3-D PSF = LSF (x) FSF.  Restated because the reference's
+# own saved cube pair (tests/input/GalPaK_*_myrun100k_{convolved,deconvolved}
+# _cube.fits) was written by it: with a cube-sized Gaussian FSF image and
+# sigma = fwhm / 2.35482 for BOTH spread functions it reproduces the pair to
+# 1e-15 (tests/test_oracle.py), which pins padding rule, LSF vector, centring
+# (fftshift + crop) and normalisation of the live 1-D code -- same pipeline,
+# one axis -- against reference-written data.
+
+def legacy_pad_cube(cube, axes=(0, 1, 2)):
+    """lib/convolution.py:50-86 (pad_cube): zero padding to 2**len(bin(n-1)) with
+    the data at offset diff/2 (+1 when diff is odd) -- the rule of `padding`,
+    lib/convolution.py:137-155, on several axes."""
+    old = cube.shape
+    new = list(old)
+    for ax in axes:
+        new[ax] = padded_length(old[ax])
+    slices = [slice(0, n) for n in old]
+    for ax in axes:
+        slices[ax] = slice(padding_offset(old[ax]), old[ax] + padding_offset(old[ax]))
+    padded = np.zeros(new)
+    padded[tuple(slices)] = cube
+    return padded, tuple(slices)
+
+
+def legacy_convolve_3d_same(cube, psf):
+    """lib/convolution.py:13-47 (convolve_3d_same): rfftn * rfftn -> irfftn ->
+    fftshift -> crop, on the padded grid (circular: "has edge effects")."""
+    padded, slices = legacy_pad_cube(cube)
+    size = padded.shape
+    padded_psf, _ = legacy_pad_cube(psf)
+    axes = (0, 1, 2)
+    fft_psf = np.fft.rfftn(padded_psf, s=size, axes=axes)
+    fft_img = np.fft.rfftn(padded, s=size, axes=axes)
+    out = np.real(np.fft.fftshift(np.fft.irfftn(fft_img * fft_psf, s=size, axes=axes), axes=axes))
+    return out[slices]
+
+
+def legacy_convolve_2d_same(image, psf):
+    """One channel of legacy_convolve_3d_same (the spatial factor of the
+    separable 3-D PSF): padded circular 2-D FFT convolution."""
+    return legacy_convolve_3d_same(image[None], psf[None])[0]
+
+
+def legacy_gaussian_fsf_full(shape, fwhm_px):
+    """The FSF image the older revision fed to convolve_3d_same: a Gaussian on the
+    cube's full spatial grid (as MoffatFieldSpreadFunction still does,
+    lib/spread_functions.py:165-189), centre (n-1)//2 - (n%2 - 1)
+    (lib/spread_functions.py:107-110), sigma = fwhm / 2.35482 (the constant of
+    lib/spread_functions.py:247), normalised to sum 1."""
+    h, w = shape
+    yo = (h - 1) // 2 - (h % 2 - 1)
+    xo = (w - 1) // 2 - (w % 2 - 1)
+    sigma = fwhm_px / 2.35482
+    y, x = np.indices(shape)
+    img = np.exp(-0.5 * ((y - yo) ** 2 + (x - xo) ** 2) / sigma ** 2)
+    return img / img.sum()
 
 
 def forward_full(shape, params, mask, fsf, lsf):

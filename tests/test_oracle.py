@@ -92,21 +92,63 @@ def test_reference_mat_fixture_known_answer():
     assert z2.std() > 1.5
 
 
-def test_reference_saved_cube_pair_known_answer():
-    """tests/input/GalPaK_*_myrun100k_{convolved,deconvolved}_cube.fits are the
-    reference's own Run.save_fits outputs (lib/run.py:797-806): the convolved
-    cube is LSF x FSF of the clean one under the MUSE defaults
-    (lib/instruments.py:95-107: Gaussian FSF fwhm 1.0"/0.2" px, Gaussian LSF fwhm
-    2.675 A/1.25 A px).  An older revision wrote them, so the agreement is 0.4 % of
-    the peak, not bit-level: a known answer for the
-    orientation, centring and normalisation of the whole convolution."""
+def _galpak_pair():
     g = gold("ref_galpak_pair.npz")
     clean, conv = g["clean"], g["convolved"]
+    # MUSE defaults (lib/instruments.py:95-107) on the pair's WCS (1.25 A, 0.2")
+    lsf = O.gaussian_lsf_vector(clean.shape[0], 2.675 / 2.35482 / 1.25)   # spread_functions.py:247
+    return clean, conv, lsf
+
+
+def test_reference_saved_cube_pair_is_reproduced_by_the_legacy_convolution():
+    """tests/input/GalPaK_*_myrun100k_{convolved,deconvolved}_cube.fits are the
+    reference's own saved outputs.  They were written by the OLDER revision's
+    convolution (lib/convolution.py:13-86, commented out today): 3-D circular
+    FFT on the power-of-two padded grid with a cube-sized Gaussian FSF image and
+    sigma = fwhm/2.35482.  Restated (oracle.legacy_*), it reproduces the pair to
+    rounding -- so the 0.4 % of the next test is fully explained, and the
+    padding rule, LSF vector, centring and normalisation are pinned bit-level."""
+    clean, conv, lsf = _galpak_pair()
+    fsf_full = O.legacy_gaussian_fsf_full(clean.shape[1:], 1.0 / 0.2)
+    out = O.legacy_convolve_3d_same(clean, lsf[:, None, None] * fsf_full[None])
+    assert np.abs(out - conv).max() <= 1e-13 * conv.max()
+
+
+def test_convolve_1d_closed_form_pinned_by_the_reference_saved_pair():
+    """The legacy 3-D PSF is separable, and its z factor is exactly convolve_1d
+    (same padding, fftshift, crop: lib/convolution.py:89-120 vs :13-47).  So the
+    live spectral path -- closed form AND verbatim FFT form, at the
+    non-power-of-two depth 30 (partial-wrap branch) -- followed by the legacy
+    spatial factor must reproduce the reference-written cube to rounding."""
+    clean, conv, lsf = _galpak_pair()
+    D, H, W = clean.shape
+    fsf_full = O.legacy_gaussian_fsf_full((H, W), 1.0 / 0.2)
+    for spectral in (O.convolve_1d_closed, O.convolve_1d_fft):
+        tmp = np.empty_like(clean)
+        for y in range(H):
+            for x in range(W):
+                tmp[:, y, x] = spectral(clean[:, y, x], lsf)
+        out = np.stack([O.legacy_convolve_2d_same(tmp[z], fsf_full) for z in range(D)])
+        assert np.abs(out - conv).max() <= 1e-13 * conv.max(), spectral.__name__
+
+
+def test_reference_saved_cube_pair_known_answer():
+    """Today's forward model (truncated 13x13 FSF renormalised to 1,
+    lib/spread_functions.py:96-131; zero-boundary convolve2d, lib/run.py:1027)
+    against the same pair: 0.4 % of the peak.  The difference is the older
+    revision's rule, not an error: an untruncated FSF (the 13x13 crop holds
+    99.56 % of the Gaussian, renormalising raises the peak by 0.44 %) and
+    circular wrap at the cube's edges (previous test)."""
+    clean, conv, _ = _galpak_pair()
     fsf = O.gaussian_fsf_image(1.0 / 0.2)
     lsf = O.gaussian_lsf_vector(clean.shape[0], 2.675 / (2 * np.sqrt(2 * np.log(2))) / 1.25)
     assert fsf.shape == (13, 13)
     out = O.convolve_cube(clean, fsf, lsf)
     assert np.abs(out - conv).max() < 5e-3 * conv.max()
+    # with the untruncated FSF the interior agrees to 1e-7 (sigma constants differ by 2e-8)
+    big = O.legacy_gaussian_fsf_full((29, 29), 1.0 / 0.2)
+    inner = (slice(None), slice(8, 22), slice(8, 22))
+    assert np.abs(O.convolve_cube(clean, big, lsf)[inner] - conv[inner]).max() < 1e-7 * conv.max()
     # neither a transposed/shifted kernel nor a wrong seeing passes this bar
     assert np.abs(O.convolve_cube(clean, O.gaussian_fsf_image(0.9 / 0.2), lsf) - conv).max() \
         > 0.1 * conv.max()
