@@ -13,10 +13,20 @@ N > 1 runs N independent chains, one per GPU (BASELINE config 5, "weak"
 scaling, no data-path collective); `--mode tiled` runs ONE chain spatially
 tiled over the ranks with halo exchange (config 4).
 
+Launch: under a launcher (RANK / WORLD_SIZE in the environment, e.g. `python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) every process is
+one rank.  Without one, `--gpus N` with N > 1 starts the N ranks itself (a child
+`torch.distributed.run` on 127.0.0.1, started before this process touches the
+GPU) and exits non-zero when fewer than N devices are visible.
+
 Prints ONE JSON line (rank 0).  Besides the contract keys it carries
-  roofline      -- the MH sweep kernel (k_mh): algorithmic bytes / launch time
-  roofline_conv -- the separable LSF (x) FSF convolution of one cube
-  cpu_baseline  -- the oracle's memory-sane numpy update loop on the host cores
+  roofline             -- the MH sweep kernel (k_mh_ws): algorithmic bytes / launch time
+  roofline_beyond_mall -- the same kernel on a 300x300x256 cube, whose residual +
+                          1/variance (369 MB) exceed the 256 MB Infinity Cache
+  roofline_conv        -- the separable LSF (x) FSF convolution of one cube
+  cpu_baseline         -- the oracle's memory-sane numpy update loop on the host cores
+  cpu_baseline_conv    -- the oracle's LSF (x) FSF convolution of one cube on the host
+  host                 -- CPU model string and core counts of the box
 """
 from __future__ import annotations
 
@@ -137,6 +147,75 @@ def cpu_baseline_faithful(budget_s):
     return n / dt, n, dt
 
 
+def cpu_baseline_conv(data, fsf, lsf, budget_s):
+    """the reference's full separable convolution
+    (_compute_error_in_one_step, lib/run.py:999-1031: convolve_1d of every
+    spectrum, then scipy convolve2d 'same' of every channel) as the oracle
+    restates it, on one host core.  The spectral loop runs over a bounded sample
+    of spaxels and is scaled to the cube; the spatial pass runs on every channel
+    until the budget is spent (then scaled too)."""
+    from oracle import deconv3d_oracle as O
+    D, H, W = data.shape
+    n_sp = min(H * W, 9000)
+    t0 = time.perf_counter()
+    tmp = np.empty((D, n_sp))
+    flat = data.reshape(D, H * W)
+    for i in range(n_sp):
+        tmp[:, i] = O.spectral_convolve(flat[:, i], lsf)
+    t_spec = (time.perf_counter() - t0) * (H * W / float(n_sp))
+    t0 = time.perf_counter()
+    nz = 0
+    for z in range(D):
+        O.spatial_convolve(data[z:z + 1], fsf)
+        nz += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    t_spat = (time.perf_counter() - t0) * (D / float(nz))
+    return t_spec + t_spat, t_spec, t_spat, n_sp, nz
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(),
+            "sched_affinity": len(os.sched_getaffinity(0))}
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start N ranks (one per GPU) as children of a
+    torch.distributed.run agent and relay rank 0's JSON line.  Nothing here touches
+    the GPU (torch.cuda.device_count() does not initialise it on this image)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and ndev < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible "
+                         "(--backend gloo rehearses the ranks on fewer devices)\n"
+                         % (args.gpus, ndev))
+        return 2
+    if ndev < 1:
+        sys.stderr.write("bench.py: no HIP device visible; there is no CPU fallback\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def measured_traffic(kernel_prefix, workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
@@ -161,6 +240,40 @@ def measured_traffic(kernel_prefix, workload):
     return best
 
 
+def beyond_mall_leg(args, local_rank, fs):
+    """The MH kernel on a 300x300x256 cube: residual + 1/variance = 369 MB, more
+    than the 256 MB Infinity Cache (MALL), so the stream cannot be cache-served as
+    the 184 MB working set of the headline cube partly is.  Priced like `roofline`."""
+    from deconv3d_amd import _lib
+    D, H, W = 256, 300, 300
+    fsf, lsf = build_taps(D, fs)
+    steps = max(2, min(args.steps, 10))
+    with _lib.Engine((D, H, W), fsf.shape, device=local_rank) as eng:
+        eng.set_taps(fsf, lsf)
+        data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 777)
+        eng.set_data(data, var, mask=None)
+        del data, var
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, float(max_b[0] ** 2), seed=777, refresh_every=0)
+        eng.residual(fetch=False)
+        eng.mh_sweeps(2, 1)
+        eng.sync()
+        eng.timer_start()
+        eng.mh_sweeps(steps, 3)
+        ms = eng.timer_stop()
+        fh, fw = fsf.shape
+        ncol = fh * fw
+        bytes_per_launch = 3 * 8 * D * window_voxels(H, W, fh, fw) // ncol
+        us = ms * 1e3 / (ncol * steps)
+        gbs = bytes_per_launch / (us * 1e-6) / 1e9
+        return {"kernel": "k_mh_ws, 300x300x256 cube (working set 369 MB > 256 MB MALL)",
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
+                "launches": ncol * steps, "residual_written_every": eng.mh_layers(),
+                "value": round(steps * H * W / (ms * 1e-3), 1), "unit_value": "spaxel-updates/s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,16 +283,23 @@ def main():
     ap.add_argument("--mode", default="ensemble", choices=["ensemble", "tiled"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the legs beside the contract line (beyond-MALL cube, uniform "
+                         "variance, Gaussian FSF, reference-layout convolution)")
     ap.add_argument("--conv-iters", type=int, default=50)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / MAX-reduce (gloo: rehearsal "
                          "of the multi-process path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     dist = None
@@ -266,6 +386,11 @@ def main():
                 # every `residual_written_every` colours and applies the pending updates
                 # in registers in between, which is why `traffic` is lower
                 "residual_written_every": eng.mh_layers()}
+    if roofline["traffic"]:
+        # HBM bytes the counters saw per launch / the same launch time (the
+        # kernel moves fewer bytes than the algorithmic 24 B per window voxel)
+        roofline["traffic_gbs"] = round(roofline["traffic"] / (avg_launch_us * 1e-6) / 1e9, 1)
+        roofline["traffic_frac"] = round(roofline["traffic_gbs"] / HBM_PEAK_GBS, 4)
 
     # ---- separable convolution roofline (north_star's second target) ---------
     # cube in -> cube out, device resident.  (a) in the reference's own (D,H,W)
@@ -328,6 +453,10 @@ def main():
     }
 
     if rank == 0:
+        out["host"] = host_info()
+    if rank == 0 and not args.no_extras and args.workload == "c3_300x300x128":
+        out["roofline_beyond_mall"] = beyond_mall_leg(args, local_rank, fs)
+    if rank == 0 and not args.no_extras:
         # the reference's default variance (Run(variance=None): one constant,
         # lib/run.py:171-178): the MH kernel does not read SLOT_IVAR at all
         assert not eng.variance_is_uniform()
@@ -351,7 +480,7 @@ def main():
                 "traffic": measured_traffic("k_mh_ws<256, true,", args.workload),
                 "note": "extra: reference default variance=None (one constant); not `value`"}
 
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         # the reference's default FSF (MUSE(): Gaussian, lib/instruments.py:95-107) is an outer
         # product: the spatial pass runs 2*11 instead of 11*11 taps and is bound by HBM
         from deconv3d_amd.spread_functions import gaussian_image
@@ -384,6 +513,15 @@ def main():
                       "cannot run)" % (n, args.workload, secs, H * W * D * H * W * 8 / 1e12),
             "host_cores_visible": cores, "numpy": np.__version__}
         out["vs_cpu"] = round(value / rate, 1)
+        ctot, cspec, cspat, n_sp, nz = cpu_baseline_conv(data, fsf, lsf, min(6.0, args.cpu_seconds))
+        out["cpu_baseline_conv"] = {
+            "value": round(1.0 / ctot, 4), "unit": "cube convolutions/s", "cores": 1, "kind": "port",
+            "seconds_per_cube": round(ctot, 3), "spectral_s": round(cspec, 3),
+            "spatial_s": round(cspat, 3),
+            "sample": "oracle convolve_1d on %d of %d spectra + scipy convolve2d 'same' on %d of %d "
+                      "channels of the same cube, scaled to the cube (lib/run.py:999-1031)"
+                      % (n_sp, H * W, nz, D),
+            "vs_gpu": round(ctot / (slots_ms * 1e-3), 1)}
         frate, fn, fsecs = cpu_baseline_faithful(min(3.0, args.cpu_seconds))
         out["cpu_baseline_faithful"] = {
             "value": round(frate, 2), "unit": "spaxel-updates/s", "cores": 1, "kind": "port",

@@ -215,3 +215,69 @@ def test_write_every_checkpoints_and_resume(tmp_path):
     again = d3d.Run(cube, inst, variance=var, initial_parameters=name + "_parameters.npy",
                     max_iterations=1)
     np.testing.assert_array_equal(again.chain[0], ck)
+
+
+def test_contribution_of_spaxel_values_match_the_oracle():
+    """Run.contribution_of_spaxel (lib/run.py:654-708) value by value against the
+    oracle's restatement: a corner, an edge, an interior and a MASKED spaxel (the
+    reference ignores the mask here), and the device chain state is untouched."""
+    from oracle import deconv3d_oracle as O
+    inst, cube, var, truth, _ = synthetic_cube(D=16, H=9, W=9, seed=6)
+    mask = np.ones((9, 9))
+    mask[5, 2] = 0
+    run = d3d.Run(cube, inst, variance=var, mask=mask, max_iterations=3, seed=2)
+    before = run.engine.get_params()
+    for (y, x) in [(0, 0), (8, 8), (0, 4), (4, 4), (5, 2)]:
+        p = truth[y, x] * np.array([1.3, 1.0, 0.8])
+        got, _ = run.contribution_of_spaxel(x, y, p, 9, 9, 16)
+        want = O.contribution_of_spaxel(x, y, p, 9, 9, 16, run.fsf, run.lsf)
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want)), (y, x)
+    np.testing.assert_array_equal(run.engine.get_params(), before)
+    # simulate_* take explicit parameters and leave the chain state alone as well
+    sim = run.simulate_convolved(cube.data.shape, truth)
+    want = O.forward_full(cube.data.shape, truth, mask, run.fsf, run.lsf)
+    assert np.max(np.abs(sim - want)) <= 1e-12 * np.max(np.abs(want))
+    np.testing.assert_array_equal(run.engine.get_params(), before)
+
+
+def test_run_on_a_cube_with_nan_voxels():
+    """A cube with one NaN voxel and one all-NaN spaxel goes through Run():
+    NaN spectra are masked (lib/run.py:157-162), the bounds stay finite
+    (lib/line_models.py:79-90 would make them NaN) and the chain moves."""
+    inst, cube, var, truth, _ = synthetic_cube(D=16, H=9, W=9, seed=9)
+    data = cube.data.copy()
+    data[3, 2, 6] = np.nan          # one voxel
+    data[:, 7, 1] = np.nan          # a whole spectrum
+    bad = inst.build_cube(data)
+    run = d3d.Run(bad, inst, variance=var, max_iterations=6, seed=5)
+    assert np.all(np.isfinite(run.max_boundaries)) and run.max_boundaries[0] > 0
+    assert run.mask[2, 6] == 0 and run.mask[7, 1] == 0 and run.mask.sum() == 79
+    live = run.mask == 1
+    assert np.all(np.isfinite(run.chain[:, live]))
+    assert not np.array_equal(run.chain[-1][live], run.chain[0][live])
+    np.testing.assert_array_equal(run.chain[-1][~live], run.chain[0][~live])
+    assert np.all(np.isfinite(run.convolved_cube.data))
+    # default variance on a NaN cube: median_clip ignores the NaNs
+    run2 = d3d.Run(bad, inst, max_iterations=2, seed=5)
+    assert np.isfinite(run2.variance_cube).all()
+
+
+def test_resume_continues_the_random_streams(tmp_path):
+    """A run resumed from a checkpoint (parameters + state) continues the sweep
+    numbering: 6 + 6 sweeps equal 12 sweeps in one go, and without the state the
+    second segment would replay the first segment's random numbers."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=4)
+    name = str(tmp_path / "ck")
+    kw = dict(variance=var, seed=3, min_acceptance_rate=0., refresh_every=0)
+    whole = d3d.Run(cube, inst, max_iterations=13, **kw)
+    first = d3d.Run(cube, inst, max_iterations=7, write_every=7, checkpoint=name, **kw)
+    state = np.load(name + "_state.npz")
+    assert int(state["iteration"]) == 7 and int(state["seed"]) == 3
+    second = d3d.Run(cube, inst, max_iterations=7, initial_parameters=name + "_parameters.npy",
+                     resume_state=name + "_state.npz", **kw)
+    np.testing.assert_array_equal(first.chain[-1], np.load(name + "_parameters.npy"))
+    # (the resumed run rebuilds the residual from the parameters: rounding-level differences)
+    np.testing.assert_allclose(second.chain[-1], whole.chain[-1], rtol=1e-8, atol=1e-8)
+    replay = d3d.Run(cube, inst, max_iterations=7, initial_parameters=name + "_parameters.npy",
+                     **kw)
+    assert not np.allclose(replay.chain[-1], whole.chain[-1], rtol=1e-3, atol=1e-3)

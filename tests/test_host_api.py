@@ -235,3 +235,19 @@ def test_run_rejects_bad_inputs_like_the_reference():
     with pytest.raises(ValueError, match="Initial params"): # lib/run.py:300-305
         d3d.Run(cube, inst, initial_parameters=np.zeros((3, 3, 3)))
 
+
+
+def test_bench_refuses_multi_gpu_without_devices():
+    """`bench.py --gpus N` without a launcher starts its own ranks -- and must exit
+    non-zero, not silently measure one GPU, when the devices are not there."""
+    import subprocess
+    import sys
+    from deconv3d_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("needs a box without HIP devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--steps", "1", "--warmup", "0"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0
+    assert "HIP device" in r.stderr and not r.stdout.strip()
