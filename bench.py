@@ -196,6 +196,8 @@ def spawn_ranks(args):
     import subprocess
     import torch
     ndev = torch.cuda.device_count()
+    if args.dry_run:
+        ndev = max(ndev, args.gpus)
     if args.backend == "nccl" and ndev < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible "
                          "(--backend gloo rehearses the ranks on fewer devices)\n"
@@ -287,6 +289,12 @@ def main():
                     help="skip the legs beside the contract line (beyond-MALL cube, uniform "
                          "variance, Gaussian FSF, reference-layout convolution)")
     ap.add_argument("--conv-iters", type=int, default=50)
+    ap.add_argument("--tiles", default=None,
+                    help="--mode tiled: tile grid TYxTX (default: row strips, N x 1); with "
+                         "--gpus 1 the tiles run as contexts of this one process (loop-back)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="start the ranks, rendezvous, report rank / seed plumbing and exit "
+                         "without touching a GPU (CPU-side test of the launcher path)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / MAX-reduce (gloo: rehearsal "
                          "of the multi-process path on a box with fewer GPUs than ranks)")
@@ -308,17 +316,40 @@ def main():
         import torch
         import torch.distributed as dist
         ndev = torch.cuda.device_count()
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not args.dry_run:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
             local_rank = local_rank % max(ndev, 1)
-            torch.cuda.set_device(local_rank)
+            if not args.dry_run:
+                torch.cuda.set_device(local_rank)
+
+    if args.dry_run:
+        # the plumbing of the self-started job, no GPU: who am I, which chain do I run
+        mine = {"rank": rank, "seed": 12345 + rank, "local_rank": local_rank}
+        everyone = [mine]
+        if dist is not None:
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup,
+                              "ranks": [e["rank"] for e in everyone],
+                              "seeds": [e["seed"] for e in everyone],
+                              "config": {"workload": args.workload,
+                                         "parallelism": "1 chain" if world == 1
+                                         else "ensemble of %d chains" % world}}))
+        return
 
     if args.mode == "tiled" and world > 1:
         from deconv3d_amd import tiling
         return tiling.bench_tiled(args, rank, local_rank, world, dist, torch)
+    if args.mode == "tiled":
+        from deconv3d_amd import tiling
+        return tiling.bench_tiled_loopback(args, local_rank)
 
     from deconv3d_amd import _lib
 

@@ -29,8 +29,15 @@ SYMBOLS = [
     "d3d_mh_config", "d3d_mh_set_sweep_origin", "d3d_window_stats",
     "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform", "d3d_mh_layers",
     "d3d_colour_count", "d3d_rtnorm",
-    "d3d_set_tile", "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
+    "d3d_set_tile", "d3d_set_parts", "d3d_mh_phase", "d3d_mh_accepted", "d3d_flush",
+    "d3d_halo_plan", "d3d_comm_unique_id", "d3d_comm_init", "d3d_comm_destroy",
+    "d3d_halo_exchange", "d3d_halo_pack", "d3d_halo_unpack", "d3d_halo_buffers",
+    "d3d_halo_download", "d3d_halo_upload", "d3d_device_copy",
+    "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
 ]
+
+PLAN_PARAMS = 16          # D3D_PLAN_PARAMS
+COMM_UID_BYTES = 128      # D3D_COMM_UID_BYTES
 
 SLOT_DATA, SLOT_IVAR, SLOT_ERR, SLOT_SIM, SLOT_TMP0, SLOT_TMP1 = range(6)
 
@@ -106,6 +113,24 @@ def load():
     lib.d3d_colour_count.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int)]
     lib.d3d_rtnorm.argtypes = [ctx_p, C.c_long] + [C.c_double] * 4 + [C.c_uint64, C.c_int, dbl_p]
     lib.d3d_set_tile.argtypes = [ctx_p] + [C.c_int] * 7
+    int_p = C.POINTER(C.c_int)
+    lib.d3d_set_parts.argtypes = [ctx_p, C.c_int, int_p, int_p]
+    lib.d3d_mh_phase.argtypes = [ctx_p, C.c_int, C.c_int]
+    lib.d3d_mh_accepted.argtypes = [ctx_p, C.POINTER(C.c_int64), C.c_int]
+    lib.d3d_flush.argtypes = [ctx_p]
+    lib.d3d_halo_plan.argtypes = [ctx_p, C.c_int, C.c_int, int_p]
+    lib.d3d_comm_unique_id.argtypes = [C.c_void_p]
+    lib.d3d_comm_init.argtypes = [ctx_p, C.c_int, C.c_int, C.c_void_p]
+    lib.d3d_comm_destroy.argtypes = [ctx_p]
+    lib.d3d_halo_exchange.argtypes = [ctx_p, C.c_int]
+    lib.d3d_halo_pack.argtypes = [ctx_p, C.c_int]
+    lib.d3d_halo_unpack.argtypes = [ctx_p, C.c_int]
+    lib.d3d_halo_buffers.argtypes = [ctx_p, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+                                     C.POINTER(C.c_size_t)]
+    lib.d3d_halo_download.argtypes = [ctx_p, C.c_int, C.c_int, dbl_p]
+    lib.d3d_halo_upload.argtypes = [ctx_p, C.c_int, C.c_int, dbl_p]
+    lib.d3d_device_copy.argtypes = [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t]
     lib.d3d_mh_colour.argtypes = [ctx_p, C.c_int, C.c_int]
     lib.d3d_export_updates.argtypes = [ctx_p, C.c_int, C.POINTER(C.c_int), dbl_p]
     lib.d3d_apply_updates.argtypes = [ctx_p, C.c_int, dbl_p]
@@ -120,6 +145,14 @@ def load():
 def source_hash():
     """Hash of the sources the loaded binary was compiled from (csrc/Makefile)."""
     return load().d3d_source_hash().decode("ascii", "replace")
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 draws it, every rank
+    passes it to Engine.comm_init)."""
+    buf = C.create_string_buffer(COMM_UID_BYTES)
+    _check(load().d3d_comm_unique_id(C.cast(buf, C.c_void_p)))
+    return buf.raw
 
 
 def device_count():
@@ -385,6 +418,76 @@ class Engine(object):
     def set_tile(self, gy0, gx0, Wg, oy0, oy1, ox0, ox1):
         _check(self._lib.d3d_set_tile(self._ctx, int(gy0), int(gx0), int(Wg), int(oy0),
                                       int(oy1), int(ox0), int(ox1)))
+
+    def set_parts(self, rects, phases):
+        """rects [n,4] = (y0, y1, x0, x1) local, phases [n]."""
+        rects = np.ascontiguousarray(rects, dtype=np.int32).reshape(-1, 4)
+        phases = np.ascontiguousarray(phases, dtype=np.int32).reshape(-1)
+        if rects.shape[0] != phases.shape[0]:
+            raise ValueError("one phase per part")
+        ip = C.POINTER(C.c_int)
+        _check(self._lib.d3d_set_parts(self._ctx, rects.shape[0], rects.ctypes.data_as(ip),
+                                       phases.ctypes.data_as(ip)))
+
+    def mh_phase(self, phase, sweep):
+        _check(self._lib.d3d_mh_phase(self._ctx, int(phase), int(sweep)))
+
+    def mh_accepted(self, reset=False):
+        n = C.c_int64(0)
+        _check(self._lib.d3d_mh_accepted(self._ctx, C.byref(n), 1 if reset else 0))
+        return n.value
+
+    def flush(self):
+        _check(self._lib.d3d_flush(self._ctx))
+
+    def halo_plan(self, plan, entries):
+        """entries [n,10] = (peer, kind, send y0,y1,x0,x1, recv y0,y1,x0,x1), local."""
+        entries = np.ascontiguousarray(entries, dtype=np.int32).reshape(-1, 10)
+        _check(self._lib.d3d_halo_plan(self._ctx, int(plan), entries.shape[0],
+                                       entries.ctypes.data_as(C.POINTER(C.c_int))))
+
+    def comm_init(self, nranks, rank, uid):
+        if len(uid) != COMM_UID_BYTES:
+            raise ValueError("uid must be %d bytes" % COMM_UID_BYTES)
+        buf = C.create_string_buffer(bytes(uid), COMM_UID_BYTES)
+        _check(self._lib.d3d_comm_init(self._ctx, int(nranks), int(rank), C.cast(buf, C.c_void_p)))
+
+    def comm_destroy(self):
+        _check(self._lib.d3d_comm_destroy(self._ctx))
+
+    def halo_exchange(self, plan):
+        _check(self._lib.d3d_halo_exchange(self._ctx, int(plan)))
+
+    def halo_pack(self, plan):
+        _check(self._lib.d3d_halo_pack(self._ctx, int(plan)))
+
+    def halo_unpack(self, plan):
+        _check(self._lib.d3d_halo_unpack(self._ctx, int(plan)))
+
+    def halo_buffers(self, plan, entry):
+        """(send pointer, send bytes, receive pointer, receive bytes) of one entry."""
+        sp, rp = C.c_void_p(None), C.c_void_p(None)
+        sb, rb = C.c_size_t(0), C.c_size_t(0)
+        _check(self._lib.d3d_halo_buffers(self._ctx, int(plan), int(entry), C.byref(sp),
+                                          C.byref(sb), C.byref(rp), C.byref(rb)))
+        return sp.value, sb.value, rp.value, rb.value
+
+    def halo_download(self, plan, entry):
+        _, nbytes, _, _ = self.halo_buffers(plan, entry)
+        out = np.empty(nbytes // 8, dtype=np.float64)
+        _check(self._lib.d3d_halo_download(self._ctx, int(plan), int(entry), _dp(out)))
+        return out
+
+    def halo_upload(self, plan, entry, values):
+        _, _, _, nbytes = self.halo_buffers(plan, entry)
+        values = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        if values.shape[0] * 8 != nbytes:
+            raise ValueError("entry expects %d doubles, got %d" % (nbytes // 8, values.shape[0]))
+        _check(self._lib.d3d_halo_upload(self._ctx, int(plan), int(entry), _dp(values)))
+
+    def device_copy(self, dst, src, nbytes):
+        _check(self._lib.d3d_device_copy(self._ctx, C.c_void_p(dst), C.c_void_p(src),
+                                         C.c_size_t(nbytes)))
 
     def mh_colour(self, colour, sweep):
         _check(self._lib.d3d_mh_colour(self._ctx, int(colour), int(sweep)))

@@ -1,6 +1,9 @@
 // C ABI of libdeconv3d_hip.so -- see include/deconv3d_hip.h.
 // Host-side context, device memory, launch geometry.  gfx950 only.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed by d3d_comm_init
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +50,21 @@ int fail(int code, const char *fmt, ...) {
         if (!(cond)) return fail(code, __VA_ARGS__); \
     } while (0)
 
+// RCCL is loaded at run time (the library stays loadable without it, and a process
+// that already holds an RCCL -- torch's -- shares that one: same soname).
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+
 int next_pow2_ref(int depth) {
     // lib/convolution.py:137-141: 2 ** len(bin(depth-1)[:-1] + '0')
     unsigned v = (unsigned)(depth - 1);
@@ -83,10 +101,40 @@ struct d3d_ctx {
     double *hwbuf = nullptr; // HW scratch (chi2 map)
     double *scal = nullptr;  // small device scalars (8 doubles)
     unsigned long long *accepted = nullptr;
-    int4 *spx = nullptr;  // work lists per colour (real spaxels first, then virtual ones)
-    std::vector<int> colour_off;   // fh*fw + 1: start of each colour's list
-    std::vector<int> colour_real;  // fh*fw: number of real spaxels of each colour
+    int4 *spx = nullptr;  // work lists per (part, colour): real spaxels first, then virtual ones
+    std::vector<int> colour_real;  // fh*fw: number of real spaxels of each colour (all parts)
     size_t spx_cap = 0;
+    // A PART is a rectangle of spaxels updated together: sweep = for every phase, for
+    // every part of the phase, for every colour class, one launch (lib/run.py:553-560
+    // declares the scan order overridable).  An unpartitioned context has one part,
+    // the whole cube (a tile: its owned rectangle).  The DOMAIN of a part is the set
+    // of cells its windows touch.
+    struct Part {
+        int y0 = 0, y1 = 0, x0 = 0, x1 = 0;      // spaxels (local)
+        int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;  // domain (local)
+        int phase = 0;
+        int layers = 1;                          // pending layers in use
+        std::vector<int> off;                    // fh*fw + 1: start of each colour's list in spx
+        std::vector<int> real;                   // fh*fw: real spaxels of each colour
+    };
+    std::vector<Part> parts;
+    std::vector<int4> part_rects;  // as given to d3d_set_parts ({y0,y1,x0,x1}; .phase apart)
+    std::vector<int> part_phase;
+    int n_phases = 1;
+    int pend_part = -1;            // part the pending layers belong to
+    // halo plans (tiled chains): per plan a list of rectangle copies to / from peers
+    struct HaloEntry {
+        int peer = 0, what = 0;                   // what: 0 = SLOT_ERR cells, 1 = parameter map
+        int sy0 = 0, sy1 = 0, sx0 = 0, sx1 = 0;  // rectangle sent (local), empty when sy1 <= sy0
+        int ry0 = 0, ry1 = 0, rx0 = 0, rx1 = 0;  // rectangle received (local)
+        size_t send_off = 0, send_n = 0, recv_off = 0, recv_n = 0;  // in doubles
+    };
+    std::vector<std::vector<HaloEntry>> plans;
+    double *halo_send = nullptr, *halo_recv = nullptr;
+    size_t halo_send_cap = 0, halo_recv_cap = 0;
+    // RCCL communicator of the tiled chain (d3d_comm_init)
+    ncclComm_t comm = nullptr;
+    int comm_rank = -1, comm_size = 0;
     std::vector<uint8_t> h_mask;
 
     bool have_taps = false, have_data = false, have_params = false, have_cfg = false;
@@ -110,7 +158,7 @@ struct d3d_ctx {
     // pending layers, oldest first: colour class and G buffer of each update that has
     // not been written into SLOT_ERR yet (k_mh_ws applies up to mh_layers of them)
     int lay_n = 0, lay_cy[3] = {-1, -1, -1}, lay_cx[3] = {-1, -1, -1}, lay_g[3] = {0, 0, 0};
-    int mh_layers = 2;            // pending layers in use (1: write the residual back every colour)
+    int mh_layers = 2;            // pending layers in use by the first part (d3d_mh_layers)
     int mh_layers_cfg = 2;        // D3D_MH_LAYERS=1|2|3; small cubes fall back to 1 unless it is set
     bool mh_layers_forced = false;
     // dataflow kernel (k_mh_flow): one launch per sweep
@@ -546,7 +594,10 @@ int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data
     }
 }
 
-void pend_clear(d3d_ctx *c) { c->lay_n = 0; }
+void pend_clear(d3d_ctx *c) {
+    c->lay_n = 0;
+    c->pend_part = -1;
+}
 
 // a G buffer that holds no pending layer
 int pend_free_buf(const d3d_ctx *c) {
@@ -605,6 +656,19 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.gy0 = c->gy0;
     P.gx0 = c->gx0;
     P.Wg = c->Wg;
+    // the domain of the part whose layers are pending (the whole cube when none are)
+    if (c->pend_part >= 0 && c->pend_part < (int)c->parts.size()) {
+        const d3d_ctx::Part &pt = c->parts[c->pend_part];
+        P.dy0 = pt.dy0;
+        P.dy1 = pt.dy1;
+        P.dx0 = pt.dx0;
+        P.dx1 = pt.dx1;
+    } else {
+        P.dy0 = 0;
+        P.dy1 = c->H;
+        P.dx0 = 0;
+        P.dx1 = c->W;
+    }
     P.mask = c->mask;
     P.n_lay = c->lay_n;
     P.write_back = 1;
@@ -774,15 +838,18 @@ int flush_pending(d3d_ctx *c) {
     fill_mh_args(c, P);
     const int NT = 256;
     const int S = NT / c->HL > 0 ? NT / c->HL : 1;
-    if (c->HL <= 256) {
-        const unsigned grid = (unsigned)((c->HW + S - 1) / S);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
-                           c->stream, P);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)c->HW),
-                           dim3(1024), 0, c->stream, P);
+    const long cells = (long)(P.dy1 - P.dy0) * (P.dx1 - P.dx0);  // of the pending part's domain
+    if (cells > 0) {
+        if (c->HL <= 256) {
+            const unsigned grid = (unsigned)((cells + S - 1) / S);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
+                               c->stream, P);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)cells),
+                               dim3(1024), 0, c->stream, P);
+        }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     pend_clear(c);
     return 0;
 }
@@ -832,66 +899,107 @@ void pick_mh_geometry(d3d_ctx *c) {
     c->mh_layers = c->mh_layers_cfg;
 }
 
+int floor_div(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// Work lists of every (part, colour class).  Colour classes are GLOBAL:
+// (cy,cx) = ((y+gy0) mod fh, (x+gx0) mod fw).  A list holds the part's real
+// spaxels (inside the part, unmasked) first, then the VIRTUAL lattice positions:
+// every other point of the class's lattice whose window intersects the part's
+// domain (masked, in another part, or up to one period outside the cube), so that
+// the windows of a launch tile the domain exactly.
 int build_colour_lists(d3d_ctx *c) {
     const int ncol = c->fh * c->fw;
     const int fhh = (c->fh - 1) / 2, fhw = (c->fw - 1) / 2;
+    // parts: as set by d3d_set_parts, else one part = the owned rectangle
+    c->parts.clear();
+    if (c->part_rects.empty()) {
+        d3d_ctx::Part pt;
+        pt.y0 = c->oy0;
+        pt.y1 = c->oy1;
+        pt.x0 = c->ox0;
+        pt.x1 = c->ox1;
+        c->parts.push_back(pt);
+        c->n_phases = 1;
+    } else {
+        c->n_phases = 1;
+        for (size_t i = 0; i < c->part_rects.size(); ++i) {
+            d3d_ctx::Part pt;
+            pt.y0 = c->part_rects[i].x;
+            pt.y1 = c->part_rects[i].y;
+            pt.x0 = c->part_rects[i].z;
+            pt.x1 = c->part_rects[i].w;
+            pt.phase = c->part_phase[i];
+            c->n_phases = std::max(c->n_phases, pt.phase + 1);
+            c->parts.push_back(pt);
+        }
+    }
     std::vector<int4> list;
     list.reserve(c->spx_cap);
-    c->colour_off.assign(ncol + 1, 0);
     c->colour_real.assign(ncol, 0);
-    // colour classes are GLOBAL: (cy,cx) = ((y+gy0) mod fh, (x+gx0) mod fw)
-    for (int cy = 0; cy < c->fh; ++cy)
-        for (int cx = 0; cx < c->fw; ++cx) {
-            const int col = cy * c->fw + cx;
-            const int ly = ((cy - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
-            const int lx = ((cx - c->gx0) % c->fw + c->fw) % c->fw;
-            c->colour_off[col] = (int)list.size();
-            // real spaxels: inside the cube, owned by this tile and unmasked
-            for (int y = ly; y < c->H; y += c->fh)
-                for (int x = lx; x < c->W; x += c->fw)
-                    if (y >= c->oy0 && y < c->oy1 && x >= c->ox0 && x < c->ox1 &&
-                        c->h_mask[(size_t)y * c->W + x])
-                        list.push_back(make_int4(y, x, 1, 0));
-            c->colour_real[col] = (int)list.size() - c->colour_off[col];
-            if (c->tiled) continue;  // tiles use the immediate scheme: no virtual positions
-            // virtual positions: every other lattice point of the class whose
-            // window still intersects the cube (masked, or up to one period out)
-            for (int y = ly - c->fh; y - fhh < c->H; y += c->fh) {
-                if (y + fhh < 0) continue;
-                for (int x = lx - c->fw; x - fhw < c->W; x += c->fw) {
-                    if (x + fhw < 0) continue;
-                    const bool inside = y >= 0 && y < c->H && x >= 0 && x < c->W;
-                    if (inside && c->h_mask[(size_t)y * c->W + x]) continue;
-                    list.push_back(make_int4(y, x, 0, 0));
-                }
-            }
-        }
-    c->colour_off[ncol] = (int)list.size();
-    if (list.size() > c->spx_cap) return fail(D3D_ERR_HIP, "internal: colour list overflow");
-    // Launches that do not fill the chip are latency chains: a second layer only adds
-    // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
-    {
+    for (d3d_ctx::Part &pt : c->parts) {
+        pt.dy0 = std::max(pt.y0 - fhh, 0);
+        pt.dy1 = std::min(pt.y1 + fhh, c->H);
+        pt.dx0 = std::max(pt.x0 - fhw, 0);
+        pt.dx1 = std::min(pt.x1 + fhw, c->W);
+        pt.off.assign(ncol + 1, 0);
+        pt.real.assign(ncol, 0);
+        const bool empty = pt.y1 <= pt.y0 || pt.x1 <= pt.x0;
         int most = 0;
-        for (int col = 0; col < ncol; ++col)
-            most = std::max(most, c->colour_off[col + 1] - c->colour_off[col]);
-        c->mh_layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
+        for (int cy = 0; cy < c->fh; ++cy)
+            for (int cx = 0; cx < c->fw; ++cx) {
+                const int col = cy * c->fw + cx;
+                const int ly = ((cy - c->gy0) % c->fh + c->fh) % c->fh;  // local residues
+                const int lx = ((cx - c->gx0) % c->fw + c->fw) % c->fw;
+                pt.off[col] = (int)list.size();
+                if (empty) continue;
+                // first lattice coordinates whose window reaches the domain
+                const int ys = ly + c->fh * floor_div(pt.dy0 - fhh - ly + c->fh - 1, c->fh);
+                const int xs = lx + c->fw * floor_div(pt.dx0 - fhw - lx + c->fw - 1, c->fw);
+                for (int y = ys; y - fhh < pt.dy1; y += c->fh)
+                    for (int x = xs; x - fhw < pt.dx1; x += c->fw)
+                        if (y >= pt.y0 && y < pt.y1 && x >= pt.x0 && x < pt.x1 &&
+                            c->h_mask[(size_t)y * c->W + x])
+                            list.push_back(make_int4(y, x, 1, 0));
+                pt.real[col] = (int)list.size() - pt.off[col];
+                c->colour_real[col] += pt.real[col];
+                for (int y = ys; y - fhh < pt.dy1; y += c->fh)
+                    for (int x = xs; x - fhw < pt.dx1; x += c->fw) {
+                        const bool is_real = y >= pt.y0 && y < pt.y1 && x >= pt.x0 && x < pt.x1 &&
+                                             c->h_mask[(size_t)y * c->W + x];
+                        if (!is_real) list.push_back(make_int4(y, x, 0, 0));
+                    }
+                most = std::max(most, (int)list.size() - pt.off[col]);
+            }
+        pt.off[ncol] = (int)list.size();
+        // Launches that do not fill the chip are latency chains: a second layer only adds
+        // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
+        pt.layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
     }
-    // tables of the dataflow kernel: active colours in order, their ticket
-    // ranges, and per colour the map lattice point -> index in its list
+    c->mh_layers = c->parts[0].layers;
+    if (list.size() > c->spx_cap) {
+        if (c->spx) (void)hipFree(c->spx);
+        c->spx = nullptr;
+        c->spx_cap = 0;
+        HIP_TRY(hipMalloc(&c->spx, list.size() * sizeof(int4)));
+        c->spx_cap = list.size();
+    }
+    // tables of the dataflow kernel (unpartitioned contexts only): active colours in
+    // order, their ticket ranges, and per colour the map lattice point -> index in its list
     c->flow_K = 0;
     c->flow_items = 0;
     c->flow_last_cy = c->flow_last_cx = -1;
-    if (!c->tiled) {
+    if (!c->tiled && c->parts.size() == 1 && list.size() <= c->flow_cap_items) {
+        const d3d_ctx::Part &pt = c->parts[0];
         std::vector<int4> ents, cols;
         std::vector<int> lat((size_t)ncol * c->flow_LY * c->flow_LX, -1);
         for (int col = 0; col < ncol; ++col) {
-            if (c->colour_real[col] <= 0) continue;
+            if (pt.real[col] <= 0) continue;
             const int cy = col / c->fw, cx = col % c->fw;  // == local residues (not tiled)
-            const int n_all = c->colour_off[col + 1] - c->colour_off[col];
+            const int n_all = pt.off[col + 1] - pt.off[col];
             const int k = (int)cols.size();
             cols.push_back(make_int4((int)ents.size(), cy, cx, 0));
             for (int i = 0; i < n_all; ++i) {
-                const int4 e = list[(size_t)c->colour_off[col] + i];
+                const int4 e = list[(size_t)pt.off[col] + i];
                 const int iy = (e.x - cy) / c->fh + 1, ix = (e.y - cx) / c->fw + 1;
                 if (iy < 0 || iy >= c->flow_LY || ix < 0 || ix >= c->flow_LX)
                     return fail(D3D_ERR_HIP, "internal: lattice index out of range");
@@ -918,6 +1026,7 @@ int build_colour_lists(d3d_ctx *c) {
         HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int4),
                                hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    pend_clear(c);
     return 0;
 }
 
@@ -1082,6 +1191,10 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     if (!c) return D3D_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->halo_send) (void)hipFree(c->halo_send);
+    if (c->halo_recv) (void)hipFree(c->halo_recv);
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
@@ -1583,6 +1696,70 @@ int d3d_window_stats(d3d_ctx *c, int y, int x, const double p_new[3], double out
     return D3D_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Every colour class of one part, for one sweep (lib/run.py:367-519 restricted to
+// the part, in colour order).
+int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
+    d3d_ctx::Part &pt = c->parts[pi];
+    const int ncol = c->fh * c->fw;
+    // deferred write-back with pending layers: the wave-specialised kernel (D <= 256);
+    // an unpartitioned context may also use the plain deferred kernel
+    const bool partitioned = c->tiled || c->parts.size() > 1;
+    const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
+    if (c->lay_n && (c->pend_part != pi || !deferred))
+        if (int rc = flush_pending(c)) return rc;
+    for (int col = 0; col < ncol; ++col) {
+        const int n_real = pt.real[col];
+        if (n_real <= 0) continue;
+        if (deferred) c->pend_part = pi;  // fill_mh_args takes the domain from it
+        d3d::MHArgs P;
+        fill_mh_args(c, P);
+        P.spx = c->spx + pt.off[col];
+        if (deferred) {
+            // real + virtual positions: the windows of this launch tile the domain
+            const int n_all = pt.off[col + 1] - pt.off[col];
+#ifdef D3D_EXPERIMENTS
+            if (c->stampbuf && c->stamp_next < c->stamp_launches &&
+                (size_t)n_all * 8 <= c->stamp_stride)
+                P.stamp = c->stampbuf + (c->stamp_next++) * c->stamp_stride;
+#endif
+            // the launch that finds `layers` layers pending applies them for good
+            P.write_back = (c->lay_n >= pt.layers) ? 1 : 0;
+            const int g_cur = pend_free_buf(c);
+            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep);
+            if (rc) return rc;
+            if (P.write_back) c->lay_n = 0;
+            // this launch's updates are the newest pending layer (local residues)
+            pend_push(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
+                      ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw, g_cur);
+            c->pend_part = pi;
+        } else {
+            int rc = launch_mh(c, P, (unsigned)n_real, sweep);
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+int run_phase(d3d_ctx *c, int phase, uint32_t sweep) {
+    for (size_t pi = 0; pi < c->parts.size(); ++pi)
+        if (c->parts[pi].phase == phase)
+            if (int rc = run_part(c, (int)pi, sweep)) return rc;
+    return 0;
+}
+
+int halo_exchange(d3d_ctx *c, int plan);
+bool plan_has_entries(const d3d_ctx *c, int plan) {
+    return plan >= 0 && plan < (int)c->plans.size() && !c->plans[plan].empty();
+}
+
+}  // namespace
+
+extern "C" {
+
 int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, double *chain_out,
                   double *dlog_out, int64_t *accepted) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
@@ -1590,47 +1767,37 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
          "taps/data/parameters/mh_config not set");
     NEED(n_sweeps >= 0 && first_sweep >= 0, D3D_ERR_INVALID, "negative sweep count/index");
     NEED(keep_one_in > 0, D3D_ERR_INVALID, "keep_one_in= MUST be a positive integer");
+    // a tile whose neighbours' updates reach it needs the halo exchange between the phases
+    bool any_plan = false;
+    for (int ph = 0; ph < c->n_phases; ++ph) any_plan = any_plan || plan_has_entries(c, ph);
+    NEED(!any_plan || c->comm, D3D_ERR_STATE,
+         "this tile has halo plans: call d3d_comm_init, or drive the phases with d3d_mh_phase "
+         "and exchange the halos yourself");
     HIP_TRY(hipSetDevice(c->device));
     if (!c->err_valid) {
         int rc = d3d_residual(c, nullptr);
         if (rc) return rc;
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
-    const int ncol = c->fh * c->fw;
     // k_mh_flow addresses SLOT_ERR through a raw buffer (32-bit byte offsets)
-    const bool flow = c->mh_flow && c->mh_defer == 1 && !c->tiled && c->Dp <= 256 &&
-                      c->flow_K > 0 && c->cube_elems * sizeof(double) < (size_t(1) << 31);
+    const bool flow = c->mh_flow && c->mh_defer == 1 && !c->tiled && c->parts.size() == 1 &&
+                      c->Dp <= 256 && c->flow_K > 0 &&
+                      c->cube_elems * sizeof(double) < (size_t(1) << 31);
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
+        const uint32_t rs = (uint32_t)s + c->sweep_origin;
         if (flow) {
-            int rc = launch_mh_flow(c, (uint32_t)s + c->sweep_origin);
+            c->pend_part = 0;
+            int rc = launch_mh_flow(c, rs);
             if (rc) return rc;
-        }
-        for (int col = 0; col < ncol && !flow; ++col) {
-            const int n_real = c->colour_real[col];
-            if (n_real <= 0) continue;
-            d3d::MHArgs P;
-            fill_mh_args(c, P);
-            P.spx = c->spx + c->colour_off[col];
-            if (c->mh_defer && !c->tiled) {
-                // real + virtual positions: the windows of this launch tile the cube
-                const int n_all = c->colour_off[col + 1] - c->colour_off[col];
-#ifdef D3D_EXPERIMENTS
-                if (c->stampbuf && c->stamp_next < c->stamp_launches &&
-                    (size_t)n_all * 8 <= c->stamp_stride)
-                    P.stamp = c->stampbuf + (c->stamp_next++) * c->stamp_stride;
-#endif
-                // the launch that finds mh_layers layers pending applies them for good
-                P.write_back = (c->lay_n >= c->mh_layers) ? 1 : 0;
-                const int g_cur = pend_free_buf(c);
-                int rc = launch_mh_defer(c, P, (unsigned)n_all, (uint32_t)s + c->sweep_origin);
+            c->pend_part = 0;
+        } else {
+            for (int ph = 0; ph < c->n_phases; ++ph) {
+                int rc = run_phase(c, ph, rs);
                 if (rc) return rc;
-                if (P.write_back) pend_clear(c);
-                // this launch's updates are the newest pending layer (local residues)
-                pend_push(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
-                          ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw, g_cur);
-            } else {
-                int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)s + c->sweep_origin);
-                if (rc) return rc;
+                if (plan_has_entries(c, ph)) {
+                    rc = halo_exchange(c, ph);
+                    if (rc) return rc;
+                }
             }
         }
         if (s % keep_one_in == 0) {  // lib/run.py:353, 430-432, 449-451
@@ -1644,8 +1811,14 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                                        (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
                                        c->stream));
         }
-        // lib/run.py:521-534: squash the error creep with a fresh residual
+        // lib/run.py:521-534: squash the error creep with a fresh residual.  A tile
+        // first gathers the parameters of the spaxels of its frame from their owners.
         if (c->refresh_every > 0 && s % c->refresh_every == 0) {
+            if (plan_has_entries(c, D3D_PLAN_PARAMS)) {
+                NEED(c->comm, D3D_ERR_STATE, "parameter gather needs d3d_comm_init");
+                int rc = halo_exchange(c, D3D_PLAN_PARAMS);
+                if (rc) return rc;
+            }
             int rc = forward_into(c, c->slot[D3D_SLOT_ERR], true);
             if (rc) return rc;
         }
@@ -1660,6 +1833,37 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     if (accepted) *accepted = (int64_t)acc;
     NEED(!flow_err, D3D_ERR_HIP, "k_mh_flow: a dependency wait timed out; the chain state is invalid");
     return D3D_OK;
+}
+
+int d3d_mh_phase(d3d_ctx *c, int phase, int sweep) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,
+         "taps/data/parameters/mh_config not set");
+    NEED(phase >= 0 && phase < c->n_phases && sweep >= 0, D3D_ERR_INVALID,
+         "phase %d / sweep %d out of range", phase, sweep);
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->err_valid) {
+        int rc = d3d_residual(c, nullptr);
+        if (rc) return rc;
+    }
+    return run_phase(c, phase, (uint32_t)sweep + c->sweep_origin);
+}
+
+int d3d_mh_accepted(d3d_ctx *c, int64_t *count, int reset) {
+    NEED(c && count, D3D_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long acc = 0;
+    HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
+    if (reset) HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *count = (int64_t)acc;
+    return D3D_OK;
+}
+
+int d3d_flush(d3d_ctx *c) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    return flush_pending(c);
 }
 
 int d3d_get_dlog(d3d_ctx *c, double *out_hw) {
@@ -1679,8 +1883,9 @@ int d3d_x_stamps_arm(d3d_ctx *c, int launches) {
     if (c->stampbuf) HIP_TRY(hipFree(c->stampbuf));
     NEED(c->have_data, D3D_ERR_STATE, "data not set");
     size_t most = 0;
-    for (size_t k = 0; k + 1 < c->colour_off.size(); ++k)
-        most = std::max(most, (size_t)(c->colour_off[k + 1] - c->colour_off[k]));
+    for (const d3d_ctx::Part &pt : c->parts)
+        for (size_t k = 0; k + 1 < pt.off.size(); ++k)
+            most = std::max(most, (size_t)(pt.off[k + 1] - pt.off[k]));
     c->stamp_stride = most * 8;
     c->stamp_launches = (size_t)launches;
     c->stamp_next = 0;
@@ -1705,7 +1910,9 @@ int d3d_x_stamps_read(d3d_ctx *c, int launch, int n, unsigned long long *out) {
 int d3d_mh_layers(d3d_ctx *c, int *out) {
     NEED(c && out, D3D_ERR_INVALID, "NULL argument");
     NEED(c->have_data, D3D_ERR_STATE, "data not set");
-    *out = (c->mh_defer && !c->tiled) ? c->mh_layers : 0;
+    const bool partitioned = c->tiled || c->parts.size() > 1;
+    const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
+    *out = deferred ? c->mh_layers : 0;
     return D3D_OK;
 }
 
@@ -1731,7 +1938,38 @@ int d3d_set_tile(d3d_ctx *c, int gy0, int gx0, int Wg, int oy0, int oy1, int ox0
     c->ox0 = ox0;
     c->ox1 = ox1;
     c->tiled = true;
+    c->part_rects.clear();  // one part: the owned rectangle (d3d_set_parts refines it)
+    c->part_phase.clear();
     pend_clear(c);
+    if (c->have_data) return build_colour_lists(c);
+    return D3D_OK;
+}
+
+int d3d_set_parts(d3d_ctx *c, int nparts, const int *rects, const int *phases) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(nparts >= 0 && nparts <= 4096 && (nparts == 0 || (rects && phases)), D3D_ERR_INVALID,
+         "bad part list");
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = flush_pending(c)) return rc;
+    std::vector<int4> rr;
+    std::vector<int> ph;
+    for (int i = 0; i < nparts; ++i) {
+        const int y0 = rects[4 * i], y1 = rects[4 * i + 1], x0 = rects[4 * i + 2],
+                  x1 = rects[4 * i + 3];
+        NEED(c->oy0 <= y0 && y0 <= y1 && y1 <= c->oy1 && c->ox0 <= x0 && x0 <= x1 && x1 <= c->ox1,
+             D3D_ERR_INVALID, "part %d [%d,%d)x[%d,%d) is not inside the owned rectangle", i, y0, y1,
+             x0, x1);
+        NEED(phases[i] >= 0 && phases[i] < D3D_PLAN_PARAMS, D3D_ERR_INVALID,
+             "phase %d of part %d out of range", phases[i], i);
+        for (size_t j = 0; j < rr.size(); ++j)  // parts must not overlap
+            NEED(y1 <= rr[j].x || rr[j].y <= y0 || x1 <= rr[j].z || rr[j].w <= x0 || y0 == y1 ||
+                     x0 == x1 || rr[j].x == rr[j].y || rr[j].z == rr[j].w,
+                 D3D_ERR_INVALID, "parts %d and %zu overlap", i, j);
+        rr.push_back(make_int4(y0, y1, x0, x1));
+        ph.push_back(phases[i]);
+    }
+    c->part_rects = rr;
+    c->part_phase = ph;
     if (c->have_data) return build_colour_lists(c);
     return D3D_OK;
 }
@@ -1748,12 +1986,16 @@ int d3d_mh_colour(d3d_ctx *c, int colour, int sweep) {
         if (rc) return rc;
     }
     if (int rc = flush_pending(c)) return rc;
-    const int n_real = c->colour_real[colour];
-    if (n_real <= 0) return D3D_OK;
-    d3d::MHArgs P;
-    fill_mh_args(c, P);
-    P.spx = c->spx + c->colour_off[colour];
-    return launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep + c->sweep_origin);
+    for (const d3d_ctx::Part &pt : c->parts) {
+        const int n_real = pt.real[colour];
+        if (n_real <= 0) continue;
+        d3d::MHArgs P;
+        fill_mh_args(c, P);
+        P.spx = c->spx + pt.off[colour];
+        int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep + c->sweep_origin);
+        if (rc) return rc;
+    }
+    return D3D_OK;
 }
 
 int d3d_export_updates(d3d_ctx *c, int n, const int *spaxels, double *out) {
@@ -1847,6 +2089,262 @@ int d3d_mh_colour_lines(d3d_ctx *c, int sweep, int n, const int *spaxels, const 
                            c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D3D_OK;
+}
+
+}  // extern "C"
+
+// ---- halo exchange of the tiled chain ------------------------------------------
+
+namespace {
+
+int load_rccl() {
+    if (g_rccl.handle) return 0;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(D3D_ERR_UNSUPPORTED, "cannot load RCCL (librccl.so.1): %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define D3D_SYM(field, name)                                                        \
+    do {                                                                            \
+        *(void **)(&a.field) = dlsym(h, name);                                      \
+        if (!a.field) return fail(D3D_ERR_UNSUPPORTED, "RCCL lacks symbol %s", name); \
+    } while (0)
+    D3D_SYM(GetUniqueId, "ncclGetUniqueId");
+    D3D_SYM(CommInitRank, "ncclCommInitRank");
+    D3D_SYM(CommDestroy, "ncclCommDestroy");
+    D3D_SYM(Send, "ncclSend");
+    D3D_SYM(Recv, "ncclRecv");
+    D3D_SYM(GroupStart, "ncclGroupStart");
+    D3D_SYM(GroupEnd, "ncclGroupEnd");
+    D3D_SYM(GetErrorString, "ncclGetErrorString");
+#undef D3D_SYM
+    g_rccl = a;
+    return 0;
+}
+
+#define RCCL_TRY(expr)                                                                  \
+    do {                                                                                \
+        ncclResult_t r_ = (expr);                                                       \
+        if (r_ != ncclSuccess)                                                          \
+            return fail(D3D_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+int rect_copy(d3d_ctx *c, int what, int y0, int y1, int x0, int x1, double *packed, int unpack) {
+    const int ny = y1 - y0, nx = x1 - x0;
+    if (ny <= 0 || nx <= 0) return 0;
+    double *arr = what == 0 ? c->slot[D3D_SLOT_ERR] : c->params;
+    const int E = what == 0 ? c->Dp : 3;
+    const long total = (long)ny * nx * E;
+    const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 8192);
+    hipLaunchKernelGGL(d3d::k_rect_copy, dim3(grid), dim3(256), 0, c->stream, arr, c->W, E, y0, x0,
+                       ny, nx, packed, unpack);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int halo_pack(d3d_ctx *c, int plan) {
+    bool err_cells = false;
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan]) err_cells = err_cells || (e.what == 0 && e.send_n);
+    // pending updates are part of the residual a neighbour must see
+    if (err_cells)
+        if (int rc = flush_pending(c)) return rc;
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan])
+        if (e.send_n)
+            if (int rc = rect_copy(c, e.what, e.sy0, e.sy1, e.sx0, e.sx1, c->halo_send + e.send_off, 0))
+                return rc;
+    return 0;
+}
+
+int halo_unpack(d3d_ctx *c, int plan) {
+    bool err_cells = false;
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan]) err_cells = err_cells || (e.what == 0 && e.recv_n);
+    if (err_cells)
+        if (int rc = flush_pending(c)) return rc;
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan])
+        if (e.recv_n)
+            if (int rc = rect_copy(c, e.what, e.ry0, e.ry1, e.rx0, e.rx1, c->halo_recv + e.recv_off, 1))
+                return rc;
+    return 0;
+}
+
+// pack -> grouped point-to-point RCCL send/recv -> unpack, all queued on the ctx
+// stream: no host synchronisation, no staging through host memory.
+int halo_exchange(d3d_ctx *c, int plan) {
+    if (!plan_has_entries(c, plan)) return 0;
+    if (!c->comm) return fail(D3D_ERR_STATE, "d3d_comm_init has not been called");
+    if (int rc = halo_pack(c, plan)) return rc;
+    RCCL_TRY(g_rccl.GroupStart());
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan]) {
+        if (e.recv_n)
+            RCCL_TRY(g_rccl.Recv(c->halo_recv + e.recv_off, e.recv_n, ncclFloat64, e.peer, c->comm,
+                                 c->stream));
+        if (e.send_n)
+            RCCL_TRY(g_rccl.Send(c->halo_send + e.send_off, e.send_n, ncclFloat64, e.peer, c->comm,
+                                 c->stream));
+    }
+    RCCL_TRY(g_rccl.GroupEnd());
+    return halo_unpack(c, plan);
+}
+
+bool plan_ok(const d3d_ctx *c, int plan) { return plan >= 0 && plan < (int)c->plans.size(); }
+
+}  // namespace
+
+extern "C" {
+
+int d3d_halo_plan(d3d_ctx *c, int plan, int n, const int *entries) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    NEED(plan >= 0 && plan <= D3D_PLAN_PARAMS, D3D_ERR_INVALID, "plan %d out of range", plan);
+    NEED(n >= 0 && n <= 64 && (n == 0 || entries), D3D_ERR_INVALID, "bad entry list");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<d3d_ctx::HaloEntry> v;
+    size_t so = 0, ro = 0;
+    for (int i = 0; i < n; ++i) {
+        const int *q = entries + 10 * i;
+        d3d_ctx::HaloEntry e;
+        e.peer = q[0];
+        e.what = q[1];
+        e.sy0 = q[2]; e.sy1 = q[3]; e.sx0 = q[4]; e.sx1 = q[5];
+        e.ry0 = q[6]; e.ry1 = q[7]; e.rx0 = q[8]; e.rx1 = q[9];
+        NEED(e.peer >= 0 && (e.what == 0 || e.what == 1), D3D_ERR_INVALID, "entry %d: bad peer/kind", i);
+        const bool s_empty = e.sy1 <= e.sy0 || e.sx1 <= e.sx0;
+        const bool r_empty = e.ry1 <= e.ry0 || e.rx1 <= e.rx0;
+        NEED(s_empty || (e.sy0 >= 0 && e.sy1 <= c->H && e.sx0 >= 0 && e.sx1 <= c->W), D3D_ERR_INVALID,
+             "entry %d: send rectangle outside the cube", i);
+        NEED(r_empty || (e.ry0 >= 0 && e.ry1 <= c->H && e.rx0 >= 0 && e.rx1 <= c->W), D3D_ERR_INVALID,
+             "entry %d: receive rectangle outside the cube", i);
+        const size_t E = e.what == 0 ? (size_t)c->Dp : 3;
+        e.send_n = s_empty ? 0 : (size_t)(e.sy1 - e.sy0) * (e.sx1 - e.sx0) * E;
+        e.recv_n = r_empty ? 0 : (size_t)(e.ry1 - e.ry0) * (e.rx1 - e.rx0) * E;
+        e.send_off = so;
+        e.recv_off = ro;
+        so += e.send_n;
+        ro += e.recv_n;
+        v.push_back(e);
+    }
+    if ((int)c->plans.size() <= plan) c->plans.resize(plan + 1);
+    c->plans[plan] = v;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // nobody may still use the old buffers
+    if (so > c->halo_send_cap) {
+        if (c->halo_send) (void)hipFree(c->halo_send);
+        c->halo_send = nullptr;
+        c->halo_send_cap = 0;
+        HIP_TRY(hipMalloc(&c->halo_send, so * sizeof(double)));
+        c->halo_send_cap = so;
+    }
+    if (ro > c->halo_recv_cap) {
+        if (c->halo_recv) (void)hipFree(c->halo_recv);
+        c->halo_recv = nullptr;
+        c->halo_recv_cap = 0;
+        HIP_TRY(hipMalloc(&c->halo_recv, ro * sizeof(double)));
+        c->halo_recv_cap = ro;
+    }
+    return D3D_OK;
+}
+
+int d3d_halo_pack(d3d_ctx *c, int plan) {
+    NEED(c && plan_ok(c, plan), D3D_ERR_INVALID, "bad ctx / plan");
+    HIP_TRY(hipSetDevice(c->device));
+    return halo_pack(c, plan);
+}
+
+int d3d_halo_unpack(d3d_ctx *c, int plan) {
+    NEED(c && plan_ok(c, plan), D3D_ERR_INVALID, "bad ctx / plan");
+    HIP_TRY(hipSetDevice(c->device));
+    return halo_unpack(c, plan);
+}
+
+int d3d_halo_buffers(d3d_ctx *c, int plan, int entry, void **send_ptr, size_t *send_bytes,
+                     void **recv_ptr, size_t *recv_bytes) {
+    NEED(c && plan_ok(c, plan), D3D_ERR_INVALID, "bad ctx / plan");
+    NEED(entry >= 0 && entry < (int)c->plans[plan].size(), D3D_ERR_INVALID, "bad entry %d", entry);
+    const d3d_ctx::HaloEntry &e = c->plans[plan][entry];
+    if (send_ptr) *send_ptr = e.send_n ? (void *)(c->halo_send + e.send_off) : nullptr;
+    if (send_bytes) *send_bytes = e.send_n * sizeof(double);
+    if (recv_ptr) *recv_ptr = e.recv_n ? (void *)(c->halo_recv + e.recv_off) : nullptr;
+    if (recv_bytes) *recv_bytes = e.recv_n * sizeof(double);
+    return D3D_OK;
+}
+
+int d3d_halo_download(d3d_ctx *c, int plan, int entry, double *host) {
+    NEED(c && plan_ok(c, plan) && host, D3D_ERR_INVALID, "bad ctx / plan / buffer");
+    NEED(entry >= 0 && entry < (int)c->plans[plan].size(), D3D_ERR_INVALID, "bad entry %d", entry);
+    const d3d_ctx::HaloEntry &e = c->plans[plan][entry];
+    HIP_TRY(hipSetDevice(c->device));
+    if (e.send_n)
+        HIP_TRY(hipMemcpyAsync(host, c->halo_send + e.send_off, e.send_n * sizeof(double),
+                               hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_halo_upload(d3d_ctx *c, int plan, int entry, const double *host) {
+    NEED(c && plan_ok(c, plan) && host, D3D_ERR_INVALID, "bad ctx / plan / buffer");
+    NEED(entry >= 0 && entry < (int)c->plans[plan].size(), D3D_ERR_INVALID, "bad entry %d", entry);
+    const d3d_ctx::HaloEntry &e = c->plans[plan][entry];
+    HIP_TRY(hipSetDevice(c->device));
+    if (e.recv_n)
+        HIP_TRY(hipMemcpyAsync(c->halo_recv + e.recv_off, host, e.recv_n * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_device_copy(d3d_ctx *c, void *dst, const void *src, size_t bytes) {
+    NEED(c && (bytes == 0 || (dst && src)), D3D_ERR_INVALID, "NULL argument");
+    if (bytes == 0) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return D3D_OK;
+}
+
+int d3d_comm_unique_id(void *uid) {
+    NEED(uid, D3D_ERR_INVALID, "uid is NULL");
+    if (int rc = load_rccl()) return rc;
+    static_assert(sizeof(ncclUniqueId) == D3D_COMM_UID_BYTES, "unexpected ncclUniqueId size");
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(uid, &id, sizeof id);
+    return D3D_OK;
+}
+
+int d3d_comm_init(d3d_ctx *c, int nranks, int rank, const void *uid) {
+    NEED(c && uid, D3D_ERR_INVALID, "NULL argument");
+    NEED(nranks >= 1 && rank >= 0 && rank < nranks, D3D_ERR_INVALID, "rank %d of %d", rank, nranks);
+    NEED(!c->comm, D3D_ERR_STATE, "communicator already initialised");
+    if (int rc = load_rccl()) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof id);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank;
+    c->comm_size = nranks;
+    return D3D_OK;
+}
+
+int d3d_comm_destroy(d3d_ctx *c) {
+    NEED(c, D3D_ERR_INVALID, "ctx is NULL");
+    if (!c->comm) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr;
+    RCCL_TRY(g_rccl.CommDestroy(comm));
+    return D3D_OK;
+}
+
+int d3d_halo_exchange(d3d_ctx *c, int plan) {
+    NEED(c && plan_ok(c, plan), D3D_ERR_INVALID, "bad ctx / plan");
+    for (const d3d_ctx::HaloEntry &e : c->plans[plan])
+        NEED(e.peer < c->comm_size, D3D_ERR_INVALID, "plan %d names peer %d of %d ranks", plan, e.peer,
+             c->comm_size);
+    HIP_TRY(hipSetDevice(c->device));
+    return halo_exchange(c, plan);
 }
 
 int d3d_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma, uint64_t seed,

@@ -1521,6 +1521,12 @@ struct MHArgs {
     // tile origin inside the global cube (multi-GPU tiling): random numbers
     // are keyed by the GLOBAL spaxel index (y+gy0)*Wg + (x+gx0).
     int gy0, gx0, Wg;
+    // DOMAIN of the launch: the cells [dy0,dy1) x [dx0,dx1) the windows of the part
+    // being updated may touch (the part's rectangle grown by the FSF half widths,
+    // clipped to the cube; the whole cube for an unpartitioned context).  The deferred
+    // kernels clip every window to it, so that pending layers of a part never reach
+    // cells another part (or another GPU's tile) is responsible for.
+    int dy0, dy1, dx0, dx1;
     // deferred write-back state
     const uint8_t *mask;  // [H*W], 1 = spaxel is iterated
     const double *Gprev;  // [slots][Dp] pending updates of colour prev_colour
@@ -1985,10 +1991,10 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
     // the <= 2 x 2 pending spaxels that cover this window
     int psy[2], psx[2];
     if (P.prev_cy >= 0) {
-        psy[0] = covering_coord(max(y - fhh, 0), P.prev_cy, P.fh, fhh, P.H);
-        psy[1] = covering_coord(min(y + fhh, P.H - 1), P.prev_cy, P.fh, fhh, P.H);
-        psx[0] = covering_coord(max(x - fhw, 0), P.prev_cx, P.fw, fhw, P.W);
-        psx[1] = covering_coord(min(x + fhw, P.W - 1), P.prev_cx, P.fw, fhw, P.W);
+        psy[0] = covering_coord(max(y - fhh, P.dy0), P.prev_cy, P.fh, fhh, P.H);
+        psy[1] = covering_coord(min(y + fhh, P.dy1 - 1), P.prev_cy, P.fh, fhh, P.H);
+        psx[0] = covering_coord(max(x - fhw, P.dx0), P.prev_cx, P.fw, fhw, P.W);
+        psx[1] = covering_coord(min(x + fhw, P.dx1 - 1), P.prev_cx, P.fw, fhw, P.W);
     } else {
         psy[0] = psy[1] = psx[0] = psx[1] = -1;
     }
@@ -1997,7 +2003,7 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
         const int dy = p / P.fw, dx = p - dy * P.fw;
         const int yy = y + dy - fhh, xx = x + dx - fhw;
         int vox = -1, tap = -1, sel = 0;
-        if (yy >= 0 && yy < P.H && xx >= 0 && xx < P.W) {
+        if (yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1) {
             vox = yy * P.W + xx;
             if (P.prev_cy >= 0) {
                 const int sy = covering_coord(yy, P.prev_cy, P.fh, fhh, P.H);
@@ -2129,10 +2135,10 @@ __device__ __forceinline__ void mh_ws_preds(const MHArgs &P, MHWsItem &I) {
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         if (j < I.n_lay) {
-            I.psy0[j] = covering_coord(max(y - fhh, 0), I.lay_cy[j], P.fh, fhh, P.H);
-            I.psy1[j] = covering_coord(min(y + fhh, P.H - 1), I.lay_cy[j], P.fh, fhh, P.H);
-            I.psx0[j] = covering_coord(max(x - fhw, 0), I.lay_cx[j], P.fw, fhw, P.W);
-            I.psx1[j] = covering_coord(min(x + fhw, P.W - 1), I.lay_cx[j], P.fw, fhw, P.W);
+            I.psy0[j] = covering_coord(max(y - fhh, P.dy0), I.lay_cy[j], P.fh, fhh, P.H);
+            I.psy1[j] = covering_coord(min(y + fhh, P.dy1 - 1), I.lay_cy[j], P.fh, fhh, P.H);
+            I.psx0[j] = covering_coord(max(x - fhw, P.dx0), I.lay_cx[j], P.fw, fhw, P.W);
+            I.psx1[j] = covering_coord(min(x + fhw, P.dx1 - 1), I.lay_cx[j], P.fw, fhw, P.W);
         } else {
             I.psy0[j] = I.psy1[j] = I.psx0[j] = I.psx1[j] = -1;
         }
@@ -2140,7 +2146,7 @@ __device__ __forceinline__ void mh_ws_preds(const MHArgs &P, MHWsItem &I) {
 }
 
 // needs mh_ws_preds.  Table row of position p: [0] local spaxel index of the voxel
-// column (-1 = outside the cube); [1+j] for layer j: tap index of that layer's
+// column (-1 = outside the launch's domain); [1+j] for layer j: tap index of that layer's
 // update there | which of its <= 4 staged G rows << 16, or -1 = none.
 template <int M>
 __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, const MHWsItem &I,
@@ -2152,7 +2158,7 @@ __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, 
         S.fsf[p] = P.fsf[p];
         const int dy = p / P.fw, dx = p - dy * P.fw;
         const int yy = y + dy - fhh, xx = x + dx - fhw;
-        const bool inside = yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+        const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
         S.pos[ROW * p] = inside ? yy * P.W + xx : -1;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -2679,9 +2685,11 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
     const int S = NT / P.HL;
     const int s = threadIdx.x / P.HL, zl = threadIdx.x - s * P.HL;
-    const long vox = (long)blockIdx.x * S + s;
-    if (s >= S || vox >= (long)P.H * P.W) return;
-    const int yy = (int)(vox / P.W), xx = (int)(vox - (long)yy * P.W);
+    const int dw = P.dx1 - P.dx0;
+    const long cell = (long)blockIdx.x * S + s;  // cell of the domain, row-major
+    if (s >= S || cell >= (long)(P.dy1 - P.dy0) * dw) return;
+    const int yy = P.dy0 + (int)(cell / dw), xx = P.dx0 + (int)(cell - (cell / dw) * dw);
+    const long vox = (long)yy * P.W + xx;
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     double2 e = *reinterpret_cast<const double2 *>(P.err + vox * P.Dp + 2 * zl);
     bool touched = false;
@@ -2690,6 +2698,8 @@ __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
         if (j >= P.n_lay) continue;
         const int sy = covering_coord(yy, P.lay_cy[j], P.fh, fhh, P.H);
         const int sx = covering_coord(xx, P.lay_cx[j], P.fw, fhw, P.W);
+        // (k_mh_ws: an unmasked lattice point outside the part being updated left a zero
+        // G row, mh_ws_zero_row; k_mh_defer leaves none for masked ones: check the mask)
         if (sy < 0 || sx < 0 || !P.mask[sy * P.W + sx]) continue;
         const double fp = P.fsf[(yy - sy + fhh) * P.fw + (xx - sx + fhw)];
         const double2 gz = *reinterpret_cast<const double2 *>(
@@ -2699,6 +2709,24 @@ __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
         touched = true;
     }
     if (touched) *reinterpret_cast<double2 *>(P.err + vox * P.Dp + 2 * zl) = e;
+}
+
+// Halo exchange of the tiled chain: the cells (all E values per spaxel: E = Dp for
+// a cube, 3 for the parameter map) of the rectangle [y0,y1) x [x0,x1) of a (H,W,E)
+// array to / from a packed buffer.  A row of the rectangle is one contiguous run.
+__global__ __launch_bounds__(256) void k_rect_copy(double *__restrict__ arr, int W, int E, int y0,
+                                                    int x0, int ny, int nx,
+                                                    double *__restrict__ packed, int unpack) {
+    const long run = (long)nx * E;
+    const long total = (long)ny * run;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long r = i / run, o = i - r * run;
+        double *cell = arr + ((long)(y0 + r) * W + x0) * E + o;
+        if (unpack)
+            *cell = packed[i];
+        else
+            packed[i] = *cell;
+    }
 }
 
 }  // namespace d3d

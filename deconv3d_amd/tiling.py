@@ -2,33 +2,53 @@
 """
 Spatial tiling of ONE chain over several GPUs (BASELINE config 4).
 
-The reference is a single process; nothing here has a counterpart in it.  An
-update at spaxel (y, x) touches only its FSF window (lib/run.py:404-419), so the
-cube is cut into ty x tx tiles of owned spaxels.  A tile's device context holds
-its owned rectangle plus a frame of FSF half-width cells.  Colour classes and
-random numbers are keyed by GLOBAL coordinates, hence every rank makes exactly
-the decisions the single-device chain makes; what a rank cannot compute itself
--- the residual change caused by a NEIGHBOUR's update whose window reaches into
-its region -- is replayed from 8-double records {y, x, a,c,w before, a,c,w after}
-(`d3d_export_updates` / `d3d_apply_updates`).  The tiled chain is therefore
-bit-identical to the single-device chain (tests/test_gpu_tiling.py,
-tests/test_tiling_cpu.py).
+The reference is a single process; nothing here has a counterpart in it.  Two of
+its properties make the tiling possible: an update at spaxel (y, x) touches only
+its FSF window (lib/run.py:404-419), and the scan order of a sweep is declared
+overridable (lib/run.py:553-560).
 
-Exchange pattern: after each colour class every rank sends the records of its
-owned spaxels lying within two FSF half-widths of a neighbour's owned rectangle
-(<= 8 neighbours, point-to-point, a few hundred bytes) -- over RCCL these ride a
-direct xGMI link each; there is no ring collective on the path.  The price is
-fh*fw dependent exchanges per sweep: at 300x300 the tiled chain is
-latency-bound and slower than one GPU; it exists for cubes/chains that must be
-split, not as the throughput mode (that is the ensemble, bench.py).
+Design (MI355X: few, large point-to-point transfers over xGMI instead of one
+small exchange per colour class):
 
-Engines are duck-typed: `mh_colour(colour, sweep)`, `export_updates(idx)`,
-`apply_updates(records)`.  The product engine is `_lib.Engine`; the CPU tests
-drive the same code with an oracle-backed engine.
+* the spaxel grid is cut into ty x tx TILES of owned spaxels; a rank stores its
+  tile plus a frame of two FSF half widths (the REGION; the cells its windows
+  touch -- tile plus one half width -- are the USED cells);
+* every tile is cut into up to four PARTS by its distance to the tile's lower /
+  right border: FF (far from both), FN (within 2 half widths of the right
+  border), NF (of the lower border), NN (of both).  A sweep runs four PHASES --
+  all FF parts, all FN, all NF, all NN -- and within a phase every part runs
+  its fh*fw colour launches.  Parts of one phase on different tiles are at least
+  one full window apart, so their windows are disjoint: a phase runs on all GPUs
+  at once WITHOUT communication, and the sweep equals a sequential scan in the
+  order (phase, colour, spaxel) -- a single device given the same parts
+  (`apply_parts`) produces the same chain bit for bit;
+* after a phase each rank sends the residual cells its parts touched that another
+  rank uses: one rectangle per neighbour (row strips: 2*fhh rows x W x D doubles
+  = 3 MB at 300x300x128, contiguous), received as a plain copy.  Two to four bulk
+  copies per sweep replace the fh*fw = 121 dependent exchanges of a per-colour
+  protocol; random numbers and colour classes are keyed by GLOBAL coordinates.
+
+Transports: RCCL inside the library (`Engine.comm_init` + `d3d_mh_sweeps`:
+pack -> ncclSend/ncclRecv -> unpack on the context's stream, no host hop);
+device-to-device copies between contexts of one process (`sweep_loopback`, the
+one-GPU rehearsal and the bit-identity tests); host-staged torch.distributed
+(gloo) for multi-process rehearsal on a box with fewer GPUs than ranks.
+
+What this buys: the colour classes of a part are a dependent chain of fh*fw
+launches, and a launch costs ~10 us however few windows it holds, so a sweep
+cannot take less than (phases) x fh*fw x 10 us.  Row strips (N x 1: two phases)
+are therefore the fast layout; 2-D grids (four phases) are supported and exact
+but slower at 300x300.  The throughput mode across GPUs is the ensemble.
+
+Engines are duck-typed (`mh_phase`, `halo_pack/unpack`, `halo_download/upload`,
+...): the product engine is `_lib.Engine`; the CPU tests drive the same code with
+an oracle-backed engine.
 """
 from __future__ import annotations
 
 import numpy as np
+
+PLAN_PARAMS = 16     # _lib.PLAN_PARAMS / D3D_PLAN_PARAMS
 
 
 def _splits(n, parts):
@@ -38,6 +58,16 @@ def _splits(n, parts):
     for i in range(parts):
         edges.append(edges[-1] + base + (1 if i < extra else 0))
     return edges
+
+
+def _intersect(a, b):
+    """Intersection of two rectangles (y0, y1, x0, x1), or None when empty."""
+    if a is None or b is None:
+        return None
+    y0, y1, x0, x1 = max(a[0], b[0]), min(a[1], b[1]), max(a[2], b[2]), min(a[3], b[3])
+    if y0 >= y1 or x0 >= x1:
+        return None
+    return (y0, y1, x0, x1)
 
 
 class TileLayout(object):
@@ -51,65 +81,147 @@ class TileLayout(object):
         self.row_edges = _splits(H, ty)
         self.col_edges = _splits(W, tx)
         self.n = ty * tx
+        # parts of one phase on neighbouring tiles must be a full window apart
+        if ty > 1 and min(np.diff(self.row_edges)) < 4 * self.fhh:
+            raise ValueError("tiles of %d rows are too short for an FSF of %d rows (need >= %d)"
+                             % (min(np.diff(self.row_edges)), fh, 4 * self.fhh))
+        if tx > 1 and min(np.diff(self.col_edges)) < 4 * self.fhw:
+            raise ValueError("tiles of %d columns are too narrow for an FSF of %d columns "
+                             "(need >= %d)" % (min(np.diff(self.col_edges)), fw, 4 * self.fhw))
 
+    # -- rectangles (global coordinates, (y0, y1, x0, x1)) -------------------------
     def owned(self, rank):
-        """Global (y0, y1, x0, x1) of the spaxels rank owns."""
+        """Spaxels rank updates."""
         iy, ix = divmod(rank, self.tx)
         return (self.row_edges[iy], self.row_edges[iy + 1],
                 self.col_edges[ix], self.col_edges[ix + 1])
 
+    def _grown(self, rect, k):
+        return (max(rect[0] - k * self.fhh, 0), min(rect[1] + k * self.fhh, self.H),
+                max(rect[2] - k * self.fhw, 0), min(rect[3] + k * self.fhw, self.W))
+
+    def used(self, rank):
+        """Cells rank's windows touch: owned + one FSF half width."""
+        return self._grown(self.owned(rank), 1)
+
     def region(self, rank):
-        """Global (y0, y1, x0, x1) of the cells rank stores: owned + FSF half widths."""
+        """Cells rank stores: owned + two half widths, so that a residual rebuilt from
+        the region's parameters (lib/run.py:521-534) is exact on the used cells."""
+        return self._grown(self.owned(rank), 2)
+
+    def parts(self, rank):
+        """[(phase, rectangle)] of rank's non-empty parts: phase 0 FF, 1 FN, 2 NF, 3 NN."""
+        iy, ix = divmod(rank, self.tx)
         y0, y1, x0, x1 = self.owned(rank)
-        return (max(y0 - self.fhh, 0), min(y1 + self.fhh, self.H),
-                max(x0 - self.fhw, 0), min(x1 + self.fhw, self.W))
+        my = 2 * self.fhh if iy < self.ty - 1 else 0     # a neighbour below
+        mx = 2 * self.fhw if ix < self.tx - 1 else 0     # a neighbour to the right
+        ys, xs = max(y0, y1 - my), max(x0, x1 - mx)
+        cand = [(0, (y0, ys, x0, xs)), (1, (y0, ys, xs, x1)),
+                (2, (ys, y1, x0, xs)), (3, (ys, y1, xs, x1))]
+        return [(ph, r) for ph, r in cand if r[0] < r[1] and r[2] < r[3]]
 
-    def _near(self, rank, other):
-        """Boolean (H, W) map of rank's owned spaxels whose window reaches into
-        other's region, i.e. within 2 half-widths of other's owned rectangle."""
-        y0, y1, x0, x1 = self.owned(rank)
-        oy0, oy1, ox0, ox1 = self.owned(other)
-        ys = np.arange(self.H)
-        xs = np.arange(self.W)
-        ymask = (ys >= y0) & (ys < y1) & (ys >= oy0 - 2 * self.fhh) & (ys < oy1 + 2 * self.fhh)
-        xmask = (xs >= x0) & (xs < x1) & (xs >= ox0 - 2 * self.fhw) & (xs < ox1 + 2 * self.fhw)
-        return ymask[:, None] & xmask[None, :]
+    @property
+    def phases(self):
+        """Phase numbers in use, in order."""
+        return sorted({ph for rank in range(self.n) for ph, _ in self.parts(rank)})
 
-    def neighbours(self, rank):
-        return [o for o in range(self.n) if o != rank and self._near(rank, o).any()]
+    def all_parts(self):
+        """Every rank's parts: given to ONE device (`apply_parts`) they make it scan
+        in the tiled chain's order."""
+        return [(ph, r) for rank in range(self.n) for ph, r in self.parts(rank)]
 
-    def send_lists(self, rank, mask):
-        """{neighbour: [global (n_c, 2) int arrays of (y, x), one per colour]} of the
-        unmasked spaxels rank must report, in the order the colour is scanned
-        (row-major inside the colour)."""
-        out = {}
-        live = np.asarray(mask) == 1
-        for nb in self.neighbours(rank):
-            sel = self._near(rank, nb) & live
-            per_colour = []
-            for cy in range(self.fh):
-                for cx in range(self.fw):
-                    ys, xs = np.nonzero(sel[cy::self.fh, cx::self.fw])
-                    per_colour.append(np.stack((cy + ys * self.fh, cx + xs * self.fw), axis=1)
-                                      .astype(np.int64))
-            out[nb] = per_colour
+    def touched(self, rank, phase):
+        """Cells rank's part of `phase` reads and writes, or None."""
+        for ph, r in self.parts(rank):
+            if ph == phase:
+                return self._grown(r, 1)
+        return None
+
+    def halo_entries(self, rank, phase):
+        """[(peer, send rectangle or None, receive rectangle or None)] after `phase`:
+        rank sends the cells it touched that the peer uses, and receives likewise."""
+        out = []
+        for peer in range(self.n):
+            if peer == rank:
+                continue
+            send = _intersect(self.touched(rank, phase), self.used(peer))
+            recv = _intersect(self.touched(peer, phase), self.used(rank))
+            if send is not None or recv is not None:
+                out.append((peer, send, recv))
         return out
+
+    def param_entries(self, rank):
+        """Parameter gather before a from-scratch residual: the owners' current
+        parameters of the spaxels in rank's frame."""
+        out = []
+        for peer in range(self.n):
+            if peer == rank:
+                continue
+            send = _intersect(self.owned(rank), self.region(peer))
+            recv = _intersect(self.owned(peer), self.region(rank))
+            if send is not None or recv is not None:
+                out.append((peer, send, recv))
+        return out
+
+    def check_disjoint(self):
+        """The defining property (tests): within a phase no two ranks touch a common cell."""
+        for ph in self.phases:
+            seen = np.zeros((self.H, self.W), dtype=np.int32)
+            for rank in range(self.n):
+                t = self.touched(rank, ph)
+                if t is not None:
+                    seen[t[0]:t[1], t[2]:t[3]] += 1
+            if seen.max() > 1:
+                return False
+        return True
+
+
+def _local(rect, origin):
+    if rect is None:
+        return (0, 0, 0, 0)
+    return (rect[0] - origin[0], rect[1] - origin[0], rect[2] - origin[2], rect[3] - origin[2])
+
+
+def plan_tables(layout, rank):
+    """{plan id: int array [n, 10]} of rank's halo plans in LOCAL coordinates, the
+    form d3d_halo_plan takes: (peer, kind, send y0,y1,x0,x1, recv y0,y1,x0,x1)."""
+    origin = layout.region(rank)
+    plans = {}
+    for ph in layout.phases:
+        rows = [(peer, 0) + _local(s, origin) + _local(r, origin)
+                for peer, s, r in layout.halo_entries(rank, ph)]
+        plans[ph] = np.array(rows, dtype=np.int32).reshape(-1, 10)
+    rows = [(peer, 1) + _local(s, origin) + _local(r, origin)
+            for peer, s, r in layout.param_entries(rank)]
+    plans[PLAN_PARAMS] = np.array(rows, dtype=np.int32).reshape(-1, 10)
+    return plans
+
+
+def apply_parts(engine, layout):
+    """Make a full-cube (single device) engine scan in the tiled chain's order."""
+    parts = layout.all_parts()
+    engine.set_parts(np.array([r for _, r in parts], dtype=np.int32),
+                     np.array([ph for ph, _ in parts], dtype=np.int32))
+
+
+def setup_tile_engine(engine, layout, rank):
+    """Parts and halo plans of `rank` on an engine whose cube is layout.region(rank)
+    (set_tile already called)."""
+    origin = layout.region(rank)
+    parts = layout.parts(rank)
+    engine.set_parts(np.array([_local(r, origin) for _, r in parts], dtype=np.int32),
+                     np.array([ph for ph, _ in parts], dtype=np.int32))
+    for plan, table in plan_tables(layout, rank).items():
+        engine.halo_plan(plan, table)
 
 
 def make_tile_engine(layout, rank, data, var, mask, fsf, lsf, params, min_b, max_b,
-                     jump_amplitude, ra, seed, device=0, err=None):
-    """`_lib.Engine` holding rank's region of the global problem.  `err` is the
-    GLOBAL initial residual (cells near a region border receive contributions
-    from spaxels outside the region, so it cannot be rebuilt from the region's
-    own parameters); when None it is computed with a temporary full-size
-    context on the same device."""
+                     jump_amplitude, ra, seed, device=0, err=None, refresh_every=0):
+    """`_lib.Engine` holding rank's region of the global problem.  The initial
+    residual is rebuilt from the region's own parameters (exact on the used cells);
+    `err`, a GLOBAL residual cube, overrides it (the bit-identity tests hand every
+    tile the very same starting residual as the single device)."""
     from . import _lib
-    if err is None:
-        with _lib.Engine(data.shape, fsf.shape, device=device) as full:
-            full.set_taps(fsf, lsf)
-            full.set_data(data, var, mask=mask)
-            full.set_params(params)
-            err = full.residual()
     ry0, ry1, rx0, rx1 = layout.region(rank)
     oy0, oy1, ox0, ox1 = layout.owned(rank)
     D = data.shape[0]
@@ -117,87 +229,98 @@ def make_tile_engine(layout, rank, data, var, mask, fsf, lsf, params, min_b, max
     eng.set_taps(fsf, lsf)
     eng.set_tile(ry0, rx0, layout.W, oy0 - ry0, oy1 - ry0, ox0 - rx0, ox1 - rx0)
     sub = (slice(None), slice(ry0, ry1), slice(rx0, rx1))
-    eng.set_data(np.ascontiguousarray(data[sub]), np.ascontiguousarray(var[sub]),
+    eng.set_data(np.ascontiguousarray(data[sub]),
+                 None if var is None else np.ascontiguousarray(var[sub]),
                  mask=np.ascontiguousarray(np.asarray(mask)[ry0:ry1, rx0:rx1]))
+    setup_tile_engine(eng, layout, rank)
     eng.set_params(np.ascontiguousarray(params[ry0:ry1, rx0:rx1]))
-    eng.mh_config(min_b, max_b, jump_amplitude, ra, seed=seed, refresh_every=0)
-    eng.upload_slot(_lib.SLOT_ERR, np.ascontiguousarray(err[sub]))
+    eng.mh_config(min_b, max_b, jump_amplitude, ra, seed=seed, refresh_every=refresh_every)
+    if err is not None:
+        eng.upload_slot(_lib.SLOT_ERR, np.ascontiguousarray(err[sub]))
+    else:
+        eng.residual(fetch=False)
     return eng
 
 
-class TileStepper(object):
-    """One rank's side of the per-colour protocol."""
+# ---- transports -----------------------------------------------------------------
 
-    def __init__(self, layout, rank, engine, mask):
-        self.layout, self.rank, self.engine = layout, rank, engine
-        self.region = layout.region(rank)
-        ry0, ry1, rx0, rx1 = self.region
-        self.local_w = rx1 - rx0
-        self.send = layout.send_lists(rank, mask)            # what I report, per neighbour
-        self.recv_counts = {nb: [len(a) for a in layout.send_lists(nb, mask)[rank]]
-                            for nb in layout.neighbours(rank)
-                            if rank in layout.neighbours(nb)}
-
-    def update(self, colour, sweep):
-        """Update my spaxels of `colour`; returns {neighbour: records[n, 8]} with
-        GLOBAL coordinates in the first two columns."""
-        self.engine.mh_colour(colour, sweep)
-        ry0, _, rx0, _ = self.region
-        out = {}
-        for nb, per_colour in self.send.items():
-            yx = per_colour[colour]
-            if len(yx) == 0:
-                continue
-            idx = (yx[:, 0] - ry0) * self.local_w + (yx[:, 1] - rx0)
-            out[nb] = self.engine.export_updates(idx.astype(np.int32))
-        return out
-
-    def replay(self, records):
-        """Apply a neighbour's records (global coordinates) to my region."""
-        if records is None or len(records) == 0:
-            return
-        rec = np.array(records, dtype=np.float64).reshape(-1, 8)
-        rec[:, 0] -= self.region[0]
-        rec[:, 1] -= self.region[2]
-        self.engine.apply_updates(rec)
+def _peer_entry(tables, peer, plan, me):
+    """Index of `peer`'s entry that talks to `me` in `plan`."""
+    t = tables[peer][plan]
+    idx = np.nonzero(t[:, 0] == me)[0]
+    return int(idx[0]) if len(idx) else None
 
 
-def sweep_loopback(steppers, sweep, ncolours):
-    """All tiles in one process (one GPU, or the CPU tests): per colour every
-    tile updates, then every tile replays what the others reported."""
-    for colour in range(ncolours):
-        outbox = [st.update(colour, sweep) for st in steppers]
-        for src, msgs in enumerate(outbox):
-            for dst, rec in msgs.items():
-                steppers[dst].replay(rec)
+def exchange_loopback(engines, tables, plan, device_copy=None):
+    """All tiles in one process: pack everywhere, copy send buffers into the peers'
+    receive buffers (device to device when `device_copy`, else through the host),
+    unpack everywhere."""
+    for eng in engines:
+        eng.halo_pack(plan)
+    for eng in engines:
+        eng.sync()          # nobody still reads the receive buffers of the previous exchange
+    for me, eng in enumerate(engines):
+        for k, row in enumerate(tables[me][plan]):
+            peer = int(row[0])
+            if row[3] <= row[2] or row[5] <= row[4]:
+                continue                                   # nothing sent to this peer
+            j = _peer_entry(tables, peer, plan, me)
+            if device_copy:
+                sp, sb, _, _ = eng.halo_buffers(plan, k)
+                _, _, rp, rb = engines[peer].halo_buffers(plan, j)
+                assert sb == rb, "halo plans of ranks %d and %d disagree" % (me, peer)
+                eng.device_copy(rp, sp, sb)
+            else:
+                engines[peer].halo_upload(plan, j, eng.halo_download(plan, k))
+    for eng in engines:
+        eng.halo_unpack(plan)
 
 
-def sweep_distributed(stepper, sweep, ncolours, dist, torch, device=None):
-    """One rank of a torch.distributed job (backend nccl = RCCL over xGMI, or
-    gloo): point-to-point exchange of the border records after each colour."""
-    rank = stepper.rank
-    for colour in range(ncolours):
-        msgs = stepper.update(colour, sweep)
-        ops, inbox = [], []
-        for nb, counts in stepper.recv_counts.items():
-            n = counts[colour]
-            if n:
-                buf = torch.empty((n, 8), dtype=torch.float64, device=device)
-                inbox.append(buf)
-                ops.append(dist.P2POp(dist.irecv, buf, nb))
-        keep = []
-        for nb, rec in msgs.items():
-            t = torch.from_numpy(np.ascontiguousarray(rec))
-            if device is not None:
-                t = t.to(device)
+def sweep_loopback(engines, layout, tables, sweep, device_copy=None, refresh=False):
+    """One sweep of every tile (one GPU, or the CPU tests): phase by phase, the halo
+    copies in between; `refresh` rebuilds the residual afterwards (lib/run.py:521-534)."""
+    for ph in layout.phases:
+        for eng in engines:
+            eng.mh_phase(ph, sweep)
+        exchange_loopback(engines, tables, ph, device_copy)
+    if refresh:
+        exchange_loopback(engines, tables, PLAN_PARAMS, device_copy)
+        for eng in engines:
+            eng.residual(fetch=False)
+
+
+def exchange_distributed(engine, table, plan, dist, torch):
+    """One rank of a torch.distributed job, host-staged (gloo rehearsal): the packed
+    send buffers go through host tensors."""
+    engine.halo_pack(plan)
+    ops, inbox, keep = [], [], []
+    for k, row in enumerate(table):
+        peer = int(row[0])
+        n_recv = max(row[7] - row[6], 0) * max(row[9] - row[8], 0)
+        if n_recv:
+            _, _, _, rb = engine.halo_buffers(plan, k)
+            buf = torch.empty(rb // 8, dtype=torch.float64)
+            inbox.append((k, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer))
+        if row[3] > row[2] and row[5] > row[4]:
+            t = torch.from_numpy(engine.halo_download(plan, k))
             keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, nb))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for buf in inbox:
-            stepper.replay(buf.cpu().numpy())
-    del rank
+            ops.append(dist.P2POp(dist.isend, t, peer))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for k, buf in inbox:
+        engine.halo_upload(plan, k, buf.numpy())
+    engine.halo_unpack(plan)
+
+
+def sweep_distributed(engine, layout, tables, sweep, dist, torch, refresh=False):
+    for ph in layout.phases:
+        engine.mh_phase(ph, sweep)
+        exchange_distributed(engine, tables[ph], ph, dist, torch)
+    if refresh:
+        exchange_distributed(engine, tables[PLAN_PARAMS], PLAN_PARAMS, dist, torch)
+        engine.residual(fetch=False)
 
 
 def gather_params(layout, rank, engine):
@@ -208,16 +331,25 @@ def gather_params(layout, rank, engine):
     return (oy0, oy1, ox0, ox1), p[oy0 - ry0:oy1 - ry0, ox0 - rx0:ox1 - rx0]
 
 
-def tile_grid_for(world):
-    """ty x tx for `world` ranks: 2 -> 1x2, 4 -> 2x2, 8 -> 2x4 (config 4)."""
-    ty = int(np.floor(np.sqrt(world)))
-    while world % ty:
-        ty -= 1
-    return ty, world // ty
+def tile_grid_for(world, H=None, fh=None):
+    """Row strips (world x 1): two phases per sweep and contiguous halos.  2-D grids
+    (2x2, 2x4) are available through `--tiles` / TileLayout(ty, tx)."""
+    return world, 1
+
+
+def parse_tiles(text, world):
+    if not text:
+        return tile_grid_for(world)
+    ty, tx = [int(v) for v in text.lower().split("x")]
+    if ty * tx != world:
+        raise ValueError("--tiles %s does not match %d ranks" % (text, world))
+    return ty, tx
 
 
 def bench_tiled(args, rank, local_rank, world, dist, torch):
-    """`bench.py --mode tiled`: one 300x300x128 chain cut over the ranks."""
+    """`bench.py --mode tiled`: one 300x300x128 chain cut over the ranks.  With the
+    nccl backend the halos travel by RCCL inside the library (d3d_mh_sweeps does
+    whole sweeps on the device); with gloo they are staged through the host."""
     import json
     import time
 
@@ -226,54 +358,127 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
 
     D, H, W, fs = B.WORKLOADS[args.workload]
     fsf, lsf = B.build_taps(D, fs)
-    ty, tx = tile_grid_for(world)
+    ty, tx = parse_tiles(getattr(args, "tiles", None), world)
     layout = TileLayout(H, W, fsf.shape[0], fsf.shape[1], ty, tx)
     # every rank builds the same global synthetic problem (seed 12345)
     mask = np.ones((H, W))
     with _lib.Engine((D, H, W), fsf.shape, device=local_rank) as full:
         full.set_taps(fsf, lsf)
         data, var, truth, init, min_b, max_b = B.synthetic_inputs(full, D, H, W, fsf, 12345)
-        full.set_data(data, var, mask=mask)
-        full.set_params(init)
-        err0 = full.residual()
     ra = float(max_b[0] ** 2)
     eng = make_tile_engine(layout, rank, data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra,
-                           12345, device=local_rank, err=err0)
-    stepper = TileStepper(layout, rank, eng, mask)
-    ncol = fsf.shape[0] * fsf.shape[1]
-    device = torch.device("cuda", local_rank) if args.backend == "nccl" else None
+                           12345, device=local_rank, refresh_every=1000)
+    del data, var
+    tables = plan_tables(layout, rank)
+    rccl = args.backend == "nccl"
+    if rccl:
+        box = [_lib.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        eng.comm_init(world, rank, box[0])
+    device = torch.device("cuda", local_rank) if rccl else None
 
     def barrier():
-        torch.cuda.synchronize()
+        eng.sync()
         dist.barrier()
-        torch.cuda.synchronize()
         eng.sync()
 
+    def run(first, n):
+        if rccl:
+            return eng.mh_sweeps(n, first)
+        eng.mh_accepted(reset=True)
+        for s in range(first, first + n):
+            sweep_distributed(eng, layout, tables, s, dist, torch,
+                              refresh=(s % 1000 == 0))
+        return eng.mh_accepted()
+
     sweep = 1
-    for _ in range(args.warmup):
-        sweep_distributed(stepper, sweep, ncol, dist, torch, device)
-        sweep += 1
+    if args.warmup > 0:
+        run(sweep, args.warmup)
+        sweep += args.warmup
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sweep_distributed(stepper, sweep, ncol, dist, torch, device)
-        sweep += 1
+    accepted = run(sweep, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device if device is not None else "cpu")
+    t = torch.tensor([dt, 0.0], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    a = torch.tensor([float(accepted)], dtype=torch.float64,
+                     device=device if device is not None else "cpu")
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    halo_bytes = sum(int((r[3] - r[2]) * (r[5] - r[4])) * eng.shape[0] * 8
+                     for ph in layout.phases for r in tables[ph])
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
         "unit": "spaxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "cube": [D, H, W],
-                   "parallelism": "1 chain tiled %dx%d, border-update replay over %s"
-                                  % (ty, tx, args.backend)},
+                   "parallelism": "1 chain tiled %dx%d, %d phases per sweep, halo copies over %s"
+                                  % (ty, tx, len(layout.phases),
+                                     "RCCL send/recv (in-library, device buffers)" if rccl
+                                     else "gloo (host-staged rehearsal)"),
+                   "halo_bytes_sent_per_sweep_rank0": halo_bytes},
+        "acceptance": round(float(a.item()) / float(args.steps * H * W), 4),
     }
+    if rccl:
+        eng.comm_destroy()
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def bench_tiled_loopback(args, device):
+    """`bench.py --mode tiled --gpus 1 --tiles TYxTX`: the tiled chain with every tile
+    a context of THIS process on one GPU, halos copied device to device -- the
+    rehearsal of config 4 a one-GPU box allows (the tiles share the GPU, so this
+    measures the protocol's overhead, not a speed-up)."""
+    import json
+    import time
+
+    from . import _lib
+    import bench as B
+
+    D, H, W, fs = B.WORKLOADS[args.workload]
+    fsf, lsf = B.build_taps(D, fs)
+    ty, tx = [int(v) for v in (args.tiles or "2x1").lower().split("x")]
+    layout = TileLayout(H, W, fsf.shape[0], fsf.shape[1], ty, tx)
+    mask = np.ones((H, W))
+    with _lib.Engine((D, H, W), fsf.shape, device=device) as full:
+        full.set_taps(fsf, lsf)
+        data, var, truth, init, min_b, max_b = B.synthetic_inputs(full, D, H, W, fsf, 12345)
+    ra = float(max_b[0] ** 2)
+    engines = [make_tile_engine(layout, r, data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra,
+                                12345, device=device) for r in range(layout.n)]
+    tables = [plan_tables(layout, r) for r in range(layout.n)]
+    sweep = 1
+    for _ in range(args.warmup):
+        sweep_loopback(engines, layout, tables, sweep, device_copy=True)
+        sweep += 1
+    for e in engines:
+        e.sync()
+        e.mh_accepted(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sweep_loopback(engines, layout, tables, sweep, device_copy=True)
+        sweep += 1
+    for e in engines:
+        e.sync()
+    dt = time.perf_counter() - t0
+    accepted = sum(e.mh_accepted() for e in engines)
+    out = {
+        "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
+        "unit": "spaxel-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": args.workload, "cube": [D, H, W],
+                   "parallelism": "1 chain tiled %dx%d as %d contexts of one process on ONE GPU "
+                                  "(loop-back rehearsal), %d phases per sweep, halos copied device "
+                                  "to device" % (ty, tx, layout.n, len(layout.phases))},
+        "acceptance": round(accepted / float(args.steps * H * W), 4),
+    }
+    for e in engines:
+        e.close()
+    print(json.dumps(out))

@@ -204,29 +204,79 @@ int d3d_variance_is_uniform(d3d_ctx *ctx, int *out);
 int d3d_mh_layers(d3d_ctx *ctx, int *out);
 
 /* ---- spatial tiling (one chain over several GPUs) --------- */
-/* The reference has no counterpart (single process).  A tile ctx holds a
- * sub-region of the global cube: its owned spaxels plus a frame of FSF
- * half-width cells.  Random numbers and colour classes are keyed by GLOBAL
- * coordinates, so the tiled chain is bit-identical to the single-device one;
- * updates of spaxels near a tile border are exchanged as 8-double records and
- * replayed by the neighbours (deconv3d_amd/tiling.py drives the exchange over
- * torch.distributed / RCCL). */
+/* The reference has no counterpart (single process).  What makes tiling possible is
+ * that an update at (y,x) touches only its FSF window (lib/run.py:404-419), and that
+ * the scan order is overridable (lib/run.py:553-560).
+ *
+ * A TILE ctx holds a sub-region of the global cube: the spaxels it owns plus a
+ * frame.  Random numbers and colour classes are keyed by GLOBAL coordinates.  The
+ * owned spaxels are cut into PARTS (rectangles), each with a PHASE number: a sweep
+ * runs the phases in order, and within a phase every part runs its fh*fw colour
+ * launches.  Parts of one phase -- on this GPU or on others -- are chosen so that
+ * their windows are disjoint (deconv3d_amd/tiling.py), so a phase runs on every
+ * GPU at once with no communication, and after it each GPU sends the residual
+ * cells it changed that a neighbour also holds: a bulk HALO copy per phase (2-4
+ * per sweep, a few MB each) instead of an exchange per colour class.  The tiled
+ * chain is bit-identical to a single ctx given the same parts (d3d_set_parts). */
 
 /* Declare this ctx a tile: its (H,W) cube is the region starting at global
  * (gy0,gx0) of a cube Wg spaxels wide; it owns local rows [oy0,oy1) and columns
  * [ox0,ox1) (other spaxels are never updated here).  Call before d3d_set_data. */
 int d3d_set_tile(d3d_ctx *ctx, int gy0, int gx0, int Wg, int oy0, int oy1, int ox0, int ox1);
+/* Cut the owned spaxels into nparts rectangles rects[4*i..] = {y0,y1,x0,x1} (local,
+ * disjoint, inside the owned rectangle) with phases[i] in [0,16).  nparts = 0
+ * restores the single part.  Spaxels in no part are not updated. */
+int d3d_set_parts(d3d_ctx *ctx, int nparts, const int *rects, const int *phases);
+/* One phase of sweep `sweep`: every colour class of every part of that phase
+ * (lib/run.py:367-519 restricted to them).  For callers that exchange the halos
+ * themselves (loop-back, host-staged transports); d3d_mh_sweeps does whole sweeps
+ * including the exchange once d3d_comm_init was called. */
+int d3d_mh_phase(d3d_ctx *ctx, int phase, int sweep);
+/* Accepted proposals since the counter was last reset (d3d_mh_sweeps resets it). */
+int d3d_mh_accepted(d3d_ctx *ctx, int64_t *count, int reset);
+/* Write pending (deferred) residual updates into SLOT_ERR now. */
+int d3d_flush(d3d_ctx *ctx);
+
+/* Halo plan `plan` (0..15: after that phase; D3D_PLAN_PARAMS: the parameter gather
+ * before a from-scratch residual, lib/run.py:521-534): n entries of 10 ints
+ * {peer rank, kind (0 residual cells, 1 parameter map), send rectangle y0,y1,x0,x1,
+ * receive rectangle y0,y1,x0,x1} in local coordinates (an empty rectangle = none). */
+#define D3D_PLAN_PARAMS 16
+int d3d_halo_plan(d3d_ctx *ctx, int plan, int n, const int *entries);
+/* RCCL transport: rank 0 draws a unique id (D3D_COMM_UID_BYTES bytes), every rank
+ * passes it to d3d_comm_init (ncclCommInitRank on the ctx's device).  Then
+ * d3d_halo_exchange(plan) = pack the send rectangles, ncclSend/ncclRecv them inside
+ * one ncclGroupStart/End on the ctx stream (point-to-point: one xGMI link per
+ * neighbour, no ring), unpack -- device buffers only, no host synchronisation. */
+#define D3D_COMM_UID_BYTES 128
+int d3d_comm_unique_id(void *uid);
+int d3d_comm_init(d3d_ctx *ctx, int nranks, int rank, const void *uid);
+int d3d_comm_destroy(d3d_ctx *ctx);
+int d3d_halo_exchange(d3d_ctx *ctx, int plan);
+/* The same exchange in steps, for other transports: pack the send rectangles into
+ * the plan's device send buffer / scatter the device receive buffer; device
+ * pointers and sizes of one entry's buffers; host staging of one entry;
+ * a device-to-device copy queued on ctx's stream (loop-back between contexts). */
+int d3d_halo_pack(d3d_ctx *ctx, int plan);
+int d3d_halo_unpack(d3d_ctx *ctx, int plan);
+int d3d_halo_buffers(d3d_ctx *ctx, int plan, int entry, void **send_ptr, size_t *send_bytes,
+                     void **recv_ptr, size_t *recv_bytes);
+int d3d_halo_download(d3d_ctx *ctx, int plan, int entry, double *host);
+int d3d_halo_upload(d3d_ctx *ctx, int plan, int entry, const double *host);
+int d3d_device_copy(d3d_ctx *ctx, void *dst, const void *src, size_t bytes);
+
 /* Number of owned unmasked spaxels of global colour (cy,cx) = ((y+gy0) mod fh,
  * (x+gx0) mod fw), colour = cy*fw + cx. */
 int d3d_colour_count(d3d_ctx *ctx, int colour, int *count);
-/* One colour class of sweep `sweep` (lib/run.py:367-519 restricted to the
- * class), residual written back immediately. */
+/* One colour class of sweep `sweep` over every part, residual written back
+ * immediately (per-colour stepping for tests and probes). */
 int d3d_mh_colour(d3d_ctx *ctx, int colour, int sweep);
-/* Records {global y, global x, a,c,w before, a,c,w after} of the last update of
- * the n listed local spaxels (y*W+x), out[n*8]. */
+/* Per-update records, the finer-grained alternative to the halo copies: {global y,
+ * global x, a,c,w before, a,c,w after} of the last update of the n listed local
+ * spaxels (y*W+x), out[n*8] ... */
 int d3d_export_updates(d3d_ctx *ctx, int n, const int *spaxels, double *out);
-/* Replay n records whose first two entries are LOCAL coordinates of this tile
- * (they may lie outside it): err += f*G on the window's part inside the tile. */
+/* ... and their replay on another ctx: the first two entries are LOCAL coordinates
+ * of this tile (they may lie outside it); err += f*G on the window's part inside. */
 int d3d_apply_updates(d3d_ctx *ctx, int n, const double *records);
 
 #ifdef __cplusplus

@@ -45,6 +45,16 @@ def make_case(name):
         D, H, W = 2, 1, 3
         fsf = O.gaussian_fsf_image(1.0)
         lsf = O.gaussian_lsf_vector(D, 0.4)
+    elif name == "tile_a":      # tiling: 5x7 asymmetric FSF, tiles >= 8 rows x 12 columns
+        D, H, W = 12, 34, 26
+        fsf = rng.random((5, 7))
+        fsf /= fsf.sum()
+        lsf = O.gaussian_lsf_vector(D, 0.8)
+    elif name == "tile_b":      # tiling: tall 9x3 FSF, tiles >= 16 rows x 4 columns
+        D, H, W = 16, 40, 18
+        fsf = np.outer(O.gaussian_fsf_image(3.0)[:, 4], [0.25, 0.5, 0.25])
+        fsf /= fsf.sum()
+        lsf = O.gaussian_lsf_vector(D, 0.9088)
     else:
         raise KeyError(name)
     y, x = np.indices((H, W))

@@ -27,9 +27,13 @@ def eng():
 
 def truncnorm_cdf(x, lo, hi, mu, sigma):
     a, b = (lo - mu) / sigma, (hi - mu) / sigma
-    # survival-function form: well conditioned in the upper tail
-    sa, sb, sx = stats.norm.sf(a), stats.norm.sf(b), stats.norm.sf((x - mu) / sigma)
-    return (sa - sx) / (sa - sb)
+    z = (np.asarray(x) - mu) / sigma
+    if a + b > 0:
+        # interval on the upper side of the mean: survival functions are well conditioned
+        sa, sb, sx = stats.norm.sf(a), stats.norm.sf(b), stats.norm.sf(z)
+        return (sa - sx) / (sa - sb)
+    ca, cb, cx = stats.norm.cdf(a), stats.norm.cdf(b), stats.norm.cdf(z)
+    return (cx - ca) / (cb - ca)
 
 
 CASES = [  # (lo, hi, mu, sigma, label)

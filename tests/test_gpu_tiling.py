@@ -1,63 +1,198 @@
 """
-GPU test of the spatial tiling on ONE device (loop-back: every tile is its own
-device context on the same GPU): the tiled chain -- global colour classes,
-Philox keyed by global spaxel index, border updates replayed from 8-double
-records by k_apply_updates -- is BIT-IDENTICAL to the single-context chain.
+GPU tests of the spatial tiling (BASELINE config 4) on ONE device: every tile is
+its own device context on the same GPU (loop-back), halos copied device to device
+or staged through the host.  The tiled chain -- global colour classes, Philox
+keyed by global spaxel index, parts / phases, bulk halo copies of residual cells --
+is BIT-IDENTICAL to a single context given the same parts, at test sizes and at
+the full 300x300x128 of config 4 (2x2, 2x4 and the default row strips).  The RCCL
+transport is exercised as far as one GPU allows: a one-rank communicator sending
+to itself.
 """
 import numpy as np
 import pytest
 
 from deconv3d_amd import _lib, tiling
+from oracle import deconv3d_oracle as O
 from tests.cases import make_case
+from tests.tiling_oracle import sweep_in_part_order
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,grid", [("c1", (2, 2)), ("c1", (1, 2)), ("odd_depth", (2, 1)),
-                                       ("moffat", (2, 2)), ("rect_fsf", (3, 2)), ("nolsf", (2, 2))])
-def test_tiled_chain_is_bit_identical_to_single_context(name, grid):
-    case = make_case(name)
+def single_context(case, lay, ra, seed, sweeps, refresh_every=0):
     D, H, W = case["D"], case["H"], case["W"]
-    fh, fw = case["fsf"].shape
-    ra, seed, sweeps = 35.0, 77, 2
-    with _lib.Engine((D, H, W), (fh, fw)) as ref:
+    with _lib.Engine((D, H, W), case["fsf"].shape) as ref:
         ref.set_taps(case["fsf"], case["lsf"])
         ref.set_data(case["data"], case["var"], mask=case["mask"])
+        if lay is not None:
+            tiling.apply_parts(ref, lay)
         ref.set_params(case["init"])
-        ref.mh_config(case["min_b"], case["max_b"], 0.1, ra, seed=seed, refresh_every=0)
+        ref.mh_config(case["min_b"], case["max_b"], 0.1, ra, seed=seed, refresh_every=refresh_every)
+        err0 = ref.residual()
         accepted = ref.mh_sweeps(sweeps, 1)
-        ref_params = ref.get_params()
-        ref_err = ref.download_slot(_lib.SLOT_ERR)
-    assert accepted > 0
-    lay = tiling.TileLayout(H, W, fh, fw, *grid)
-    engines = [tiling.make_tile_engine(lay, r, case["data"], case["var"], case["mask"], case["fsf"],
-                                       case["lsf"], case["init"], case["min_b"], case["max_b"], 0.1,
-                                       ra, seed) for r in range(lay.n)]
-    try:
-        steppers = [tiling.TileStepper(lay, r, engines[r], case["mask"]) for r in range(lay.n)]
-        for s in range(1, sweeps + 1):
-            tiling.sweep_loopback(steppers, s, fh * fw)
-        live = case["mask"] == 1
-        for r in range(lay.n):
-            (y0, y1, x0, x1), p = tiling.gather_params(lay, r, engines[r])
-            m = live[y0:y1, x0:x1]
+        return ref.get_params(), ref.download_slot(_lib.SLOT_ERR), accepted, err0
+
+
+def tiled_contexts(case, lay, ra, seed, err0, refresh_every=0):
+    return [tiling.make_tile_engine(lay, r, case["data"], case["var"], case["mask"], case["fsf"],
+                                    case["lsf"], case["init"], case["min_b"], case["max_b"], 0.1,
+                                    ra, seed, err=err0, refresh_every=refresh_every)
+            for r in range(lay.n)]
+
+
+def compare(case, lay, engines, ref_params, ref_err, exact=True):
+    live = case["mask"] == 1
+    for r in range(lay.n):
+        (y0, y1, x0, x1), p = tiling.gather_params(lay, r, engines[r])
+        m = live[y0:y1, x0:x1]
+        uy0, uy1, ux0, ux1 = lay.used(r)
+        ry0, _, rx0, _ = lay.region(r)
+        err = engines[r].download_slot(_lib.SLOT_ERR)[:, uy0 - ry0:uy1 - ry0, ux0 - rx0:ux1 - rx0]
+        if exact:
             np.testing.assert_array_equal(p[m], ref_params[y0:y1, x0:x1][m])
-            ry0, ry1, rx0, rx1 = lay.region(r)
-            np.testing.assert_array_equal(engines[r].download_slot(_lib.SLOT_ERR),
-                                          ref_err[:, ry0:ry1, rx0:rx1])
+            np.testing.assert_array_equal(err, ref_err[:, uy0:uy1, ux0:ux1])
+        else:
+            np.testing.assert_allclose(p[m], ref_params[y0:y1, x0:x1][m], rtol=1e-8, atol=1e-8)
+            np.testing.assert_allclose(err, ref_err[:, uy0:uy1, ux0:ux1], rtol=0,
+                                       atol=1e-9 * np.abs(ref_err).max())
+
+
+@pytest.mark.parametrize("name,grid,device_copy", [
+    ("tile_a", (2, 2), True), ("tile_a", (4, 1), True), ("tile_a", (1, 2), False),
+    ("tile_b", (2, 3), True), ("tile_b", (2, 1), False), ("c1", (1, 1), True)])
+def test_tiled_chain_is_bit_identical_to_single_context(name, grid, device_copy):
+    case = make_case(name)
+    fh, fw = case["fsf"].shape
+    ra, seed, sweeps = 35.0, 77, 3
+    lay = tiling.TileLayout(case["H"], case["W"], fh, fw, *grid)
+    ref_params, ref_err, accepted, err0 = single_context(case, lay, ra, seed, sweeps)
+    assert accepted > 0
+    engines = tiled_contexts(case, lay, ra, seed, err0)
+    try:
+        tables = [tiling.plan_tables(lay, r) for r in range(lay.n)]
+        for s in range(1, sweeps + 1):
+            tiling.sweep_loopback(engines, lay, tables, s, device_copy=device_copy)
+        compare(case, lay, engines, ref_params, ref_err)
+        assert sum(e.mh_accepted() for e in engines) == accepted
     finally:
         for e in engines:
             e.close()
 
 
+def test_single_context_with_parts_follows_the_oracle_in_part_order():
+    """d3d_set_parts changes the scan order only: the partitioned single context
+    equals the oracle run in (phase, part, colour) order."""
+    case = make_case("tile_a")
+    fh, fw = case["fsf"].shape
+    lay = tiling.TileLayout(case["H"], case["W"], fh, fw, 2, 2)
+    st = O.MHState(case["data"], case["var"], case["mask"], case["fsf"], case["lsf"],
+                   case["init"], case["min_b"], case["max_b"], 0.1, 35.0, 77)
+    for s in (1, 2):
+        sweep_in_part_order(st, lay, s)
+    params, err, accepted, _ = single_context(case, lay, 35.0, 77, 2)
+    np.testing.assert_allclose(params, st.params, rtol=1e-9, atol=1e-9)
+    assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
+    assert accepted == st.accepted
+    # and differs from the unpartitioned order (it IS another scan order)
+    plain, _, _, _ = single_context(case, None, 35.0, 77, 2)
+    assert not np.array_equal(plain, params)
+
+
+def test_tiled_refresh_gathers_parameters_and_rebuilds_the_residual():
+    """lib/run.py:521-534 in a tiled run (refresh every 2nd sweep): parameter gather,
+    then each tile's own from-scratch residual -- rounding-level agreement with the
+    single context (the convolution kernels sum in a position-dependent order)."""
+    case = make_case("tile_b")
+    fh, fw = case["fsf"].shape
+    lay = tiling.TileLayout(case["H"], case["W"], fh, fw, 2, 2)
+    ref_params, ref_err, _, _ = single_context(case, lay, 35.0, 5, 4, refresh_every=2)
+    engines = tiled_contexts(case, lay, 35.0, 5, None, refresh_every=2)
+    try:
+        tables = [tiling.plan_tables(lay, r) for r in range(lay.n)]
+        for s in range(1, 5):
+            tiling.sweep_loopback(engines, lay, tables, s, device_copy=True, refresh=(s % 2 == 0))
+        compare(case, lay, engines, ref_params, ref_err, exact=False)
+    finally:
+        for e in engines:
+            e.close()
+
+
+@pytest.mark.parametrize("grid", [(2, 2), (2, 4), (4, 1), (8, 1)])
+def test_config4_full_size_tiled_chain_is_bit_identical(grid):
+    """BASELINE config 4 at its real size: 300x300x128, Moffat 11x11, 17-tap LSF,
+    heteroscedastic variance; four / eight tile contexts in loop-back on one GPU,
+    two sweeps (180 000 updates), parameters and residual bit-identical."""
+    import bench as B
+    D, H, W, fs = B.WORKLOADS["c3_300x300x128"]
+    fsf, lsf = B.build_taps(D, fs)
+    with _lib.Engine((D, H, W), fsf.shape) as full:
+        full.set_taps(fsf, lsf)
+        data, var, truth, init, min_b, max_b = B.synthetic_inputs(full, D, H, W, fsf, 12345)
+    mask = np.ones((H, W))
+    mask[17, 200] = mask[151, 149] = mask[150, 150] = 0
+    case = dict(D=D, H=H, W=W, fsf=fsf, lsf=lsf, data=data, var=var, mask=mask, init=init,
+                min_b=min_b, max_b=max_b)
+    lay = tiling.TileLayout(H, W, fs, fs, *grid)
+    ra = float(max_b[0] ** 2)
+    ref_params, ref_err, accepted, err0 = single_context(case, lay, ra, 12345, 2)
+    engines = tiled_contexts(case, lay, ra, 12345, err0)
+    try:
+        tables = [tiling.plan_tables(lay, r) for r in range(lay.n)]
+        for s in (1, 2):
+            tiling.sweep_loopback(engines, lay, tables, s, device_copy=True)
+        compare(case, lay, engines, ref_params, ref_err)
+        assert sum(e.mh_accepted() for e in engines) == accepted
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_rccl_halo_exchange_one_rank_sends_to_itself():
+    """The in-library RCCL transport as far as one GPU allows: a one-rank communicator
+    (ncclCommInitRank) whose plan sends a rectangle of residual cells and one of the
+    parameter map to ITSELF (pack -> ncclSend/ncclRecv in a group -> unpack on the
+    context's stream)."""
+    case = make_case("tile_a")
+    D, H, W = case["D"], case["H"], case["W"]
+    with _lib.Engine((D, H, W), case["fsf"].shape) as eng:
+        eng.set_taps(case["fsf"], case["lsf"])
+        eng.set_data(case["data"], case["var"], mask=case["mask"])
+        eng.set_params(case["init"])
+        err = eng.residual()
+        eng.comm_init(1, 0, _lib.comm_unique_id())
+        eng.halo_plan(0, [[0, 0, 2, 9, 3, 11, 20, 27, 10, 18],
+                          [0, 1, 0, 4, 0, 26, 30, 34, 0, 26]])
+        eng.halo_exchange(0)
+        got = eng.download_slot(_lib.SLOT_ERR)
+        want = err.copy()
+        want[:, 20:27, 10:18] = err[:, 2:9, 3:11]
+        np.testing.assert_array_equal(got, want)
+        p = eng.get_params()
+        wantp = np.array(case["init"])
+        wantp[30:34] = case["init"][0:4]
+        np.testing.assert_array_equal(p, wantp)
+        eng.comm_destroy()
+
+
+def test_mh_sweeps_refuses_a_tile_with_halo_plans_but_no_communicator():
+    case = make_case("tile_a")
+    lay = tiling.TileLayout(case["H"], case["W"], *case["fsf"].shape, 2, 1)
+    eng = tiling.make_tile_engine(lay, 0, case["data"], case["var"], case["mask"], case["fsf"],
+                                  case["lsf"], case["init"], case["min_b"], case["max_b"], 0.1,
+                                  10.0, 1)
+    try:
+        with pytest.raises(RuntimeError):
+            eng.mh_sweeps(1, 1)
+    finally:
+        eng.close()
+
+
 def test_colour_counts_respect_ownership():
-    case = make_case("c1")
+    case = make_case("tile_a")
     fh, fw = case["fsf"].shape
     lay = tiling.TileLayout(case["H"], case["W"], fh, fw, 2, 2)
     total = np.zeros(fh * fw, int)
-    engines = [tiling.make_tile_engine(lay, r, case["data"], case["var"], case["mask"], case["fsf"],
-                                       case["lsf"], case["init"], case["min_b"], case["max_b"], 0.1,
-                                       10.0, 1) for r in range(lay.n)]
+    engines = tiled_contexts(case, lay, 10.0, 1, None)
     try:
         for e in engines:
             total += np.array([e.colour_count(c) for c in range(fh * fw)])
@@ -70,3 +205,34 @@ def test_colour_counts_respect_ownership():
             if case["mask"][y, x] == 1:
                 want[(y % fh) * fw + (x % fw)] += 1
     np.testing.assert_array_equal(total, want)
+
+
+def test_update_records_replay_on_another_context():
+    """The finer-grained alternative to halo copies (d3d_mh_colour /
+    d3d_export_updates / d3d_apply_updates): the 8-double records of one colour
+    class, replayed on a second context, reproduce the first one's residual."""
+    case = make_case("c1")
+    D, H, W = case["D"], case["H"], case["W"]
+    fh, fw = case["fsf"].shape
+
+    def ctx():
+        e = _lib.Engine((D, H, W), (fh, fw))
+        e.set_taps(case["fsf"], case["lsf"])
+        e.set_data(case["data"], case["var"], mask=case["mask"])
+        e.set_params(case["init"])
+        e.mh_config(case["min_b"], case["max_b"], 0.1, 35.0, seed=3, refresh_every=0)
+        e.residual(fetch=False)
+        return e
+    a, b = ctx(), ctx()
+    try:
+        for colour in (0, 40, 80):
+            a.mh_colour(colour, 1)
+            cy, cx = divmod(colour, fw)
+            ys, xs = np.nonzero(case["mask"][cy::fh, cx::fw] == 1)
+            idx = (cy + ys * fh) * W + (cx + xs * fw)
+            b.apply_updates(a.export_updates(idx.astype(np.int32)))
+        np.testing.assert_array_equal(b.download_slot(_lib.SLOT_ERR), a.download_slot(_lib.SLOT_ERR))
+        np.testing.assert_array_equal(b.get_params(), a.get_params())
+    finally:
+        a.close()
+        b.close()
