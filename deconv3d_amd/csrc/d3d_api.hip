@@ -17,6 +17,7 @@
 
 #include "../../include/deconv3d_hip.h"
 #include "d3d_kernels.h"
+#include "d3d_conv.h"
 
 #define D3D_VERSION 200  // 0.2.0
 #ifndef D3D_SOURCE_HASH
@@ -186,6 +187,9 @@ struct d3d_ctx {
     double *sep_uv = nullptr;     // [fh + fw] on the device
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
+    double *fsf_quad = nullptr;   // [(fhh+1)^2] quadrant taps of an x/y-symmetric square FSF (k_conv_rows)
+    bool lsf_dense_sym = false;   // dense LSF weights mirror-symmetric bit for bit
+    int conv_rows = 1;            // D3D_CONV_ROWS=0: never use the one-pass kernel k_conv_rows
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
@@ -561,8 +565,82 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
     return 0;
 }
 
+// ---- one-pass kernel k_conv_rows (d3d_conv.h) ---------------------------------------
+// Usable for a 128-channel spectrum (one wavefront per column) and a square FSF with
+// both mirror symmetries; with_lsf additionally needs the dense power-of-two LSF form.
+bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
+    if (!c->conv_rows || c->Dp != d3d::CONV_DP) return false;
+    if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
+    if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D)) return false;
+    switch (c->fw) {
+        case 3: case 5: case 7: case 9: case 11: case 13: return true;
+        default: return false;
+    }
+}
+
+template <int FS, bool LSF, bool LSYM, bool RESID>
+int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
+    constexpr int NW = 15;
+    d3d::ConvRowsArgs A;
+    A.H = c->H;
+    A.W = c->W;
+    A.ngx = (c->W + NW - 1) / NW;
+    // one workgroup per CU (1024 threads, ~93 KB of LDS): as many row strips as fill the
+    // chip in ONE round
+    const int cus = c->flow_grid > 0 ? c->flow_grid / 4 : 256;
+    int ngy = std::max(1, cus / A.ngx);
+    ngy = std::min(ngy, c->H);
+    A.HY = (c->H + ngy - 1) / ngy;
+    if (const char *e = getenv("D3D_CONV_HY")) {
+        const int v = atoi(e);
+        if (v >= 1) A.HY = v;
+    }
+    A.ngy = (c->H + A.HY - 1) / A.HY;
+    A.quad = c->fsf_quad;
+    A.wl = c->lsf_dense;
+    A.data = data;
+    A.xcd_remap = 1;
+    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID>;
+    constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW>();
+    static bool attr_set = false;  // (per instantiation)
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
+                       in, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int FS>
+int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+    const bool sym = c->lsf_dense_sym;
+    if (lsf) {
+        if (data) return sym ? launch_conv_rows_t<FS, true, true, true>(c, in, out, data)
+                             : launch_conv_rows_t<FS, true, false, true>(c, in, out, data);
+        return sym ? launch_conv_rows_t<FS, true, true, false>(c, in, out, data)
+                   : launch_conv_rows_t<FS, true, false, false>(c, in, out, data);
+    }
+    if (data) return launch_conv_rows_t<FS, false, false, true>(c, in, out, data);
+    return launch_conv_rows_t<FS, false, false, false>(c, in, out, data);
+}
+
+int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+    switch (c->fw) {
+        case 3: return launch_conv_rows_fs<3>(c, in, out, data, lsf);
+        case 5: return launch_conv_rows_fs<5>(c, in, out, data, lsf);
+        case 7: return launch_conv_rows_fs<7>(c, in, out, data, lsf);
+        case 9: return launch_conv_rows_fs<9>(c, in, out, data, lsf);
+        case 11: return launch_conv_rows_fs<11>(c, in, out, data, lsf);
+        default: return launch_conv_rows_fs<13>(c, in, out, data, lsf);
+    }
+}
+
 // True when the spatial pass can apply the LSF itself (fused epilogue).
 bool can_fuse_lsf(const d3d_ctx *c) {
+    if (conv_rows_usable(c, true)) return true;
     if (!c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
     const bool sep = c->fsf_sep && c->sep_fuse;  // k_spatial_sep_lsf
 #ifndef D3D_EXPERIMENTS
@@ -582,6 +660,9 @@ bool can_fuse_lsf(const d3d_ctx *c) {
 // fuse_lsf: also apply the LSF along z (only when can_fuse_lsf()).
 int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
                    bool fuse_lsf = false) {
+    // an outer-product FSF keeps its own one-pass kernel (2*FS instead of (FHH+1)^2 FMAs)
+    const bool sep_path = c->fsf_sep && c->march_mode > 0 && (!fuse_lsf || c->sep_fuse);
+    if (!sep_path && conv_rows_usable(c, fuse_lsf)) return launch_conv_rows(c, in, out, data, fuse_lsf);
     int nt = pick_nt(c->HL);
     if (const char *e = getenv("D3D_SPATIAL_NT")) {
         const int v = atoi(e);
@@ -1139,6 +1220,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->mask, (size_t)c->HW));
     CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->sep_uv, (size_t)(fh + fw) * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->fsf_quad, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_shift, (size_t)c->N * sizeof(int)));
     CTX_TRY(hipMalloc(&c->lsf_weight, (size_t)c->N * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_dense, (2 * d3d::LSF_RL + 1) * sizeof(double)));
@@ -1200,7 +1282,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
-                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf};
+                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -1288,6 +1370,17 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
                                    hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // uv goes out of scope
     }
+    if (c->fsf_symx && c->fsf_symy && c->fh == c->fw) {
+        // quadrant taps quad[a][m] = fsf[fhh-a][m], a, m = 0..fhh (k_conv_rows)
+        const int fhh = (c->fh - 1) / 2, nq = fhh + 1;
+        std::vector<double> quad((size_t)nq * nq);
+        for (int a = 0; a < nq; ++a)
+            for (int m = 0; m < nq; ++m) quad[(size_t)a * nq + m] = fsf[(fhh - a) * c->fw + m];
+        HIP_TRY(hipMemcpyAsync(c->fsf_quad, quad.data(), quad.size() * sizeof(double),
+                               hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (const char *e = getenv("D3D_CONV_ROWS")) c->conv_rows = atoi(e);
     if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
     if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
     if (const char *e = getenv("D3D_MARCH_ONE")) c->march_one = atoi(e);
@@ -1358,6 +1451,9 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
             dense[sg + d3d::LSF_RL] += weight[t];
         }
         if (ok) {
+            c->lsf_dense_sym = true;
+            for (int j = 0; j < d3d::LSF_RL; ++j)
+                c->lsf_dense_sym = c->lsf_dense_sym && dense[j] == dense[2 * d3d::LSF_RL - j];
             HIP_TRY(hipMemcpyAsync(c->lsf_dense, dense.data(), dense.size() * sizeof(double),
                                    hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1768,8 +1864,14 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     NEED(n_sweeps >= 0 && first_sweep >= 0, D3D_ERR_INVALID, "negative sweep count/index");
     NEED(keep_one_in > 0, D3D_ERR_INVALID, "keep_one_in= MUST be a positive integer");
     // a tile whose neighbours' updates reach it needs the halo exchange between the phases
+    // phases of a sweep: this tile's own, and those after which a neighbour sends to it
     bool any_plan = false;
-    for (int ph = 0; ph < c->n_phases; ++ph) any_plan = any_plan || plan_has_entries(c, ph);
+    int n_phases = c->n_phases;
+    for (int ph = 0; ph < D3D_PLAN_PARAMS; ++ph)
+        if (plan_has_entries(c, ph)) {
+            any_plan = true;
+            n_phases = std::max(n_phases, ph + 1);
+        }
     NEED(!any_plan || c->comm, D3D_ERR_STATE,
          "this tile has halo plans: call d3d_comm_init, or drive the phases with d3d_mh_phase "
          "and exchange the halos yourself");
@@ -1791,7 +1893,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
             if (rc) return rc;
             c->pend_part = 0;
         } else {
-            for (int ph = 0; ph < c->n_phases; ++ph) {
+            for (int ph = 0; ph < n_phases; ++ph) {
                 int rc = run_phase(c, ph, rs);
                 if (rc) return rc;
                 if (plan_has_entries(c, ph)) {
@@ -1839,7 +1941,8 @@ int d3d_mh_phase(d3d_ctx *c, int phase, int sweep) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,
          "taps/data/parameters/mh_config not set");
-    NEED(phase >= 0 && phase < c->n_phases && sweep >= 0, D3D_ERR_INVALID,
+    // (a tile may have no part in a phase its neighbours have: then there is nothing to do)
+    NEED(phase >= 0 && phase < D3D_PLAN_PARAMS && sweep >= 0, D3D_ERR_INVALID,
          "phase %d / sweep %d out of range", phase, sweep);
     HIP_TRY(hipSetDevice(c->device));
     if (!c->err_valid) {

@@ -1,0 +1,120 @@
+"""
+k_conv_rows (csrc/d3d_conv.h): the one-pass LSF (x) FSF convolution for 128-channel
+cubes and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
+register rings + LSF epilogue -- against the oracle's restatement of
+lib/convolution.py:89-120 and lib/run.py:1027-1029, and against the two-pass
+kernels it replaces (D3D_CONV_ROWS=0).  Shapes chosen to hit every border case of
+the kernel's geometry: widths that are not a multiple of the 15 columns a workgroup
+owns, strips of unequal height, fewer rows than the FSF, single columns.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from deconv3d_amd import _lib
+from oracle import deconv3d_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def engine(shape, fsf, lsf, conv_rows=True, hy=None):
+    old = {k: os.environ.get(k) for k in ("D3D_CONV_ROWS", "D3D_CONV_HY")}
+    os.environ["D3D_CONV_ROWS"] = "1" if conv_rows else "0"
+    if hy is not None:
+        os.environ["D3D_CONV_HY"] = str(hy)
+    try:
+        eng = _lib.Engine(shape, fsf.shape)
+        eng.set_taps(fsf, lsf)          # the environment is read here
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return eng
+
+
+def lsf_asym(D, rng):
+    """Dense asymmetric taps within +-8 channels of the centre (lib/spread_functions.py:251)."""
+    v = np.zeros(D)
+    zc = (D - 1) // 2 - (D % 2 - 1)
+    v[zc - 8:zc + 9] = rng.random(17)
+    return v / v.sum()
+
+
+CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
+    (128, 23, 19, 11, "muse", None),
+    (128, 31, 17, 11, "asym", 7),
+    (128, 9, 47, 9, "muse", 4),
+    (128, 40, 15, 7, "none", None),
+    (128, 5, 16, 11, "asym", None),       # fewer rows than the FSF
+    (128, 33, 1, 5, "muse", 6),           # a single column
+    (128, 26, 31, 13, "asym", 9),
+    (128, 12, 30, 3, "muse", None),
+    (127, 14, 22, 11, "muse", None),      # padded depth: LSF not power-of-two -> FSF pass only
+]
+
+
+@pytest.mark.parametrize("D,H,W,fs,lsf_kind,hy", CASES)
+def test_one_pass_convolution_matches_the_oracle_and_the_two_pass_kernels(D, H, W, fs, lsf_kind, hy):
+    rng = np.random.default_rng(D * 1000 + H * 31 + W)
+    fsf = O.moffat_cropped(fs, 3.0, 2.5)
+    lsf = {"muse": O.muse_like_lsf(D), "asym": lsf_asym(D, rng), "none": None}[lsf_kind]
+    cube = rng.normal(size=(D, H, W))
+    want = O.convolve_cube(cube, fsf, lsf) if lsf is not None else O.spatial_convolve(cube, fsf)
+    outs = []
+    for conv_rows in (True, False):
+        with engine((D, H, W), fsf, lsf, conv_rows, hy) as eng:
+            eng.upload_slot(_lib.SLOT_TMP0, cube)
+            eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+            outs.append(eng.download_slot(_lib.SLOT_SIM))
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(outs[0] - want)) <= 1e-12 * scale
+    assert np.max(np.abs(outs[1] - want)) <= 1e-12 * scale
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-13 * scale
+
+
+@pytest.mark.parametrize("D,H,W,fs,hy", [(128, 21, 34, 11, 8), (128, 17, 16, 9, None)])
+def test_forward_model_and_residual_through_the_one_pass_kernel(D, H, W, fs, hy):
+    """params -> lines -> FSF, plain and with the data - sim epilogue
+    (lib/run.py:999-1031), with masked spaxels."""
+    rng = np.random.default_rng(7)
+    fsf = O.moffat_cropped(fs, 3.0, 2.5)
+    lsf = O.muse_like_lsf(D)
+    params = np.dstack((1 + 9 * rng.random((H, W)), D * (0.2 + 0.6 * rng.random((H, W))),
+                        0.8 + 3 * rng.random((H, W))))
+    mask = np.ones((H, W))
+    mask[3, 5] = mask[H - 1, W - 1] = 0
+    data = rng.normal(size=(D, H, W))
+    var = 0.5 + rng.random((D, H, W))
+    want = O.forward_full((D, H, W), params, mask, fsf, lsf)
+    with engine((D, H, W), fsf, lsf, True, hy) as eng:
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(params)
+        sim = eng.forward()
+        err = eng.residual()
+    assert np.max(np.abs(sim - want)) <= 1e-12 * np.max(np.abs(want))
+    assert np.max(np.abs(err - (data - want))) <= 1e-12 * np.max(np.abs(data - want))
+
+
+def test_one_pass_kernel_is_position_independent():
+    """The march always runs top-down: a cube cut out of a larger one (with the FSF
+    half width of context) gives the very same bits on the common interior -- which is
+    what lets a tile rebuild its residual and agree with the full cube."""
+    rng = np.random.default_rng(11)
+    D, H, W, fs = 128, 44, 37, 11
+    fsf = O.moffat_cropped(fs, 3.0, 2.5)
+    lsf = O.muse_like_lsf(D)
+    cube = rng.normal(size=(D, H, W))
+    with engine((D, H, W), fsf, lsf, True, 13) as eng:
+        eng.upload_slot(_lib.SLOT_TMP0, cube)
+        eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+        full = eng.download_slot(_lib.SLOT_SIM)
+    y0, y1, x0, x1 = 9, 40, 6, 33
+    with engine((D, y1 - y0, x1 - x0), fsf, lsf, True, 9) as eng:
+        eng.upload_slot(_lib.SLOT_TMP0, np.ascontiguousarray(cube[:, y0:y1, x0:x1]))
+        eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+        part = eng.download_slot(_lib.SLOT_SIM)
+    h = fs // 2
+    np.testing.assert_array_equal(part[:, h:-h, h:-h], full[:, y0 + h:y1 - h, x0 + h:x1 - h])
