@@ -188,6 +188,7 @@ struct d3d_ctx {
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *fsf_quad = nullptr;   // [(fhh+1)^2] quadrant taps of an x/y-symmetric square FSF (k_conv_rows)
+    bool fsf_symt = false;        // ... and fsf[k][i] == fsf[i][k] bit for bit (radial FSFs)
     bool lsf_dense_sym = false;   // dense LSF weights mirror-symmetric bit for bit
     int conv_rows = 1;            // D3D_CONV_ROWS=0: never use the one-pass kernel k_conv_rows
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
@@ -578,7 +579,7 @@ bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     }
 }
 
-template <int FS, bool LSF, bool LSYM, bool RESID>
+template <int FS, bool LSF, bool LSYM, bool RESID, bool TSYM>
 int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
     constexpr int NW = 15;
     d3d::ConvRowsArgs A;
@@ -596,11 +597,8 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
         if (v >= 1) A.HY = v;
     }
     A.ngy = (c->H + A.HY - 1) / A.HY;
-    A.quad = c->fsf_quad;
-    A.wl = c->lsf_dense;
-    A.data = data;
     A.xcd_remap = 1;
-    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID>;
+    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM>;
     constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW>();
     static bool attr_set = false;  // (per instantiation)
     if (!attr_set) {
@@ -609,22 +607,28 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
-                       in, out);
+                       in, out, (const double *)c->fsf_quad, (const double *)c->lsf_dense, data);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int FS>
-int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+template <int FS, bool TSYM>
+int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
     const bool sym = c->lsf_dense_sym;
     if (lsf) {
-        if (data) return sym ? launch_conv_rows_t<FS, true, true, true>(c, in, out, data)
-                             : launch_conv_rows_t<FS, true, false, true>(c, in, out, data);
-        return sym ? launch_conv_rows_t<FS, true, true, false>(c, in, out, data)
-                   : launch_conv_rows_t<FS, true, false, false>(c, in, out, data);
+        if (data) return sym ? launch_conv_rows_t<FS, true, true, true, TSYM>(c, in, out, data)
+                             : launch_conv_rows_t<FS, true, false, true, TSYM>(c, in, out, data);
+        return sym ? launch_conv_rows_t<FS, true, true, false, TSYM>(c, in, out, data)
+                   : launch_conv_rows_t<FS, true, false, false, TSYM>(c, in, out, data);
     }
-    if (data) return launch_conv_rows_t<FS, false, false, true>(c, in, out, data);
-    return launch_conv_rows_t<FS, false, false, false>(c, in, out, data);
+    if (data) return launch_conv_rows_t<FS, false, false, true, TSYM>(c, in, out, data);
+    return launch_conv_rows_t<FS, false, false, false, TSYM>(c, in, out, data);
+}
+
+template <int FS>
+int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+    if (c->fsf_symt) return launch_conv_rows_ts<FS, true>(c, in, out, data, lsf);
+    return launch_conv_rows_ts<FS, false>(c, in, out, data, lsf);
 }
 
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
@@ -1371,11 +1375,16 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
         HIP_TRY(hipStreamSynchronize(c->stream));  // uv goes out of scope
     }
     if (c->fsf_symx && c->fsf_symy && c->fh == c->fw) {
-        // quadrant taps quad[a][m] = fsf[fhh-a][m], a, m = 0..fhh (k_conv_rows)
+        // quadrant taps by distance from the centre: quad[a][e] = fsf[fhh-a][fhh-e] (k_conv_rows)
         const int fhh = (c->fh - 1) / 2, nq = fhh + 1;
         std::vector<double> quad((size_t)nq * nq);
+        c->fsf_symt = true;
         for (int a = 0; a < nq; ++a)
-            for (int m = 0; m < nq; ++m) quad[(size_t)a * nq + m] = fsf[(fhh - a) * c->fw + m];
+            for (int m = 0; m < nq; ++m) {
+                quad[(size_t)a * nq + m] = fsf[(fhh - a) * c->fw + (fhh - m)];
+                c->fsf_symt = c->fsf_symt &&
+                              fsf[(fhh - a) * c->fw + (fhh - m)] == fsf[(fhh - m) * c->fw + (fhh - a)];
+            }
         HIP_TRY(hipMemcpyAsync(c->fsf_quad, quad.data(), quad.size() * sizeof(double),
                                hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

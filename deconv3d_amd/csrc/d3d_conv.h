@@ -32,16 +32,24 @@
 namespace d3d {
 
 struct ConvRowsArgs {
-    int H, W, HY;        // cube rows / columns, output rows per strip
-    int ngx, ngy;        // column groups, row strips
-    const double *quad;  // [(FHH+1)^2] quadrant taps: quad[a*(FHH+1)+m] = fsf[FHH-a][m]
-    const double *wl;    // dense LSF weights [2*LSF_RL+1] (used when LSF)
-    const double *data;  // residual epilogue: out = data - conv (used when RESID)
+    int H, W, HY;  // cube rows / columns, output rows per strip
+    int ngx, ngy;  // column groups, row strips
     int xcd_remap;
 };
+// The tap tables come as separate `const double *__restrict__` kernel arguments (not
+// inside the struct): only then does the compiler know that nothing this kernel stores
+// can alias them, loads them with scalar loads ONCE, and keeps them in SGPRs for the
+// whole march (v_fma_f64 takes one scalar operand).  Through a struct member they were
+// re-fetched with vector global loads in every step, each a full memory latency on the
+// critical path (measured: 107 us per cube instead of 5x).
+//   quad  [(FHH+1)^2] quadrant taps by distance from the centre tap,
+//         quad[a*(FHH+1)+e] = fsf[FHH-a][FHH-e]; TSYM: the FSF is also symmetric under
+//         transposition (quad[a][e] == quad[e][a]: every radial FSF), only e <= a is read
+//   wl    dense LSF weights [2*LSF_RL+1] (LSF); LSYM: mirror-symmetric, first RL+1 read
+//   data  residual epilogue out = data - conv (RESID)
 
 constexpr int CONV_DP = 128;  // doubles per spectrum: one wavefront of z-pairs
-constexpr int CONV_NBUF = 3;  // LDS ring of input rows
+constexpr int CONV_NBUF = 4;  // LDS ring of input rows: two PAIRS (one read, one in flight)
 
 template <int FS, int NW>
 __host__ __device__ constexpr size_t conv_rows_lds_bytes() {
@@ -56,10 +64,151 @@ __device__ __forceinline__ void conv_glds16(const double *gsrc, double *lds_dst)
         (__attribute__((address_space(3))) void *)lds_dst, 16, 0, 0);
 }
 
-template <int FS, int NW, bool LSF, bool LSYM, bool RESID>
+// One step of a compute wavefront: input row r = y0 - FHH + i from LDS into the ring,
+// output row r - FHH out.  PH = i mod FS (static ring indices).
+// Range tests are kept to ONE bit test per tap row: a contribution to an output row
+// outside the strip lands in a ring slot that is never stored (the slot of a row above
+// the strip is overwritten when it turns into the newest slot, rows below never
+// finish), so the two slot updates of a tap row need no test of their own, and an
+// input row outside the cube is a row of zeros the loader wrote.  `need` has bit a set
+// when tap rows FHH-a / FHH+a reach an output row of the strip at all: that skips the
+// dot products of the first and last FHH steps (10 % of a strip's FMAs) for one scalar
+// bit test each.
+template <int FS, int NW, bool LSF, bool RESID, int PH>
+__device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long rowstride, int x,
+                                               int wave, int lane, const double *rows,
+                                               double *myspec,
+                                               const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
+                                               const double (&w)[2 * LSF_RL + 1],
+                                               const double *__restrict__ data,
+                                               double *__restrict__ out, double2 (&ring)[FS],
+                                               double2 &dnext) {
+    constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, NC = NW + FS - 1, DP = CONV_DP;
+    constexpr int NBUF = CONV_NBUF, RL = LSF_RL;
+    const int oy = y0 - 2 * FHH + i;  // the output row this step finishes
+    const bool store = oy >= y0;      // (oy < yend always: i < nsteps)
+    // tap rows at distance a from the centre reach output rows r-a and r+a, r = y0-FHH+i:
+    // inside the strip iff  0 <= i-FHH-a < n  or  0 <= i-FHH+a < n
+    const int n = yend - y0, d = i - FHH;
+    unsigned need = 0;
+#pragma unroll
+    for (int a = 0; a <= FHH; ++a)
+        need |= (unsigned)(((unsigned)(d - a) < (unsigned)n) || ((unsigned)(d + a) < (unsigned)n)) << a;
+    const double2 dcur = dnext;
+    if constexpr (RESID) {
+        // one step ahead: the data row of the output finished by step i+1
+        if (oy + 1 >= y0 && oy + 1 < yend)
+            dnext = *reinterpret_cast<const double2 *>(data + (long)(oy + 1) * rowstride +
+                                                       (long)x * DP + 2 * lane);
+    }
+    {
+        const double *rb = rows + ((size_t)(i % NBUF) * NC + wave) * DP + 2 * lane;
+        // P[e]: the two inputs at distance e from the output's column, folded
+        double2 P[NQ];
+        P[0] = *reinterpret_cast<const double2 *>(rb + (size_t)FHH * DP);
+#pragma unroll
+        for (int e = 1; e <= FHH; ++e) {
+            const double2 lo = *reinterpret_cast<const double2 *>(rb + (size_t)(FHH - e) * DP);
+            const double2 hi = *reinterpret_cast<const double2 *>(rb + (size_t)(FHH + e) * DP);
+            P[e].x = lo.x + hi.x;
+            P[e].y = lo.y + hi.y;
+        }
+#if defined(D3D_CONV_DIAG) && D3D_CONV_DIAG == 2
+        ring[PH % FS].x += P[0].x + P[1].x + P[2].x + P[FHH].x;  // diagnostic: no stencil math
+        ring[PH % FS].y += P[0].y + P[1].y + P[2].y + P[FHH].y;
+#else
+#pragma unroll
+        for (int a = 0; a <= FHH; ++a) {
+            // tap rows FHH-a and FHH+a are equal: one dot product for the two output rows
+            if (!((need >> a) & 1u)) {
+                if (a == FHH) ring[(PH + 2 * FHH) % FS] = make_double2(0.0, 0.0);
+                continue;
+            }
+            double2 T;
+            T.x = q[a][0] * P[0].x;
+            T.y = q[a][0] * P[0].y;
+#pragma unroll
+            for (int e = 1; e < NQ; ++e) {
+                T.x = fma(q[a][e], P[e].x, T.x);
+                T.y = fma(q[a][e], P[e].y, T.y);
+            }
+            ring[(PH + FHH - a) % FS].x += T.x;
+            ring[(PH + FHH - a) % FS].y += T.y;
+            if (a == FHH) {
+                // the newest slot (the one that finished last step) starts here
+                ring[(PH + 2 * FHH) % FS] = T;
+            } else if (a > 0) {
+                ring[(PH + FHH + a) % FS].x += T.x;
+                ring[(PH + FHH + a) % FS].y += T.y;
+            }
+        }
+#endif
+    }
+    if (store) {
+        double2 v = ring[PH % FS];
+        if constexpr (LSF) {
+            // LSF on the finished row: spectrum -> wave-private LDS buffer with a circular
+            // halo of RL channels -> aligned 16-byte window reads
+            *reinterpret_cast<double2 *>(myspec + RL + 2 * lane) = v;
+            if (2 * lane < RL) *reinterpret_cast<double2 *>(myspec + DP + RL + 2 * lane) = v;
+            if (2 * lane >= DP - RL) *reinterpret_cast<double2 *>(myspec + RL + 2 * lane - DP) = v;
+            __builtin_amdgcn_wave_barrier();  // LDS is in order per wavefront
+            const double *bt = myspec + 2 * lane;
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < RL + 1; ++j) {
+                const double2 p = *reinterpret_cast<const double2 *>(bt + 2 * j);
+                // p = (s[2j], s[2j+1]); acc.x = sum w[k] s[k], acc.y = sum w[k] s[k+1]
+                if (2 * j <= 2 * RL) acc.x = fma(w[2 * j], p.x, acc.x);
+                if (2 * j + 1 <= 2 * RL) acc.x = fma(w[2 * j + 1], p.y, acc.x);
+                if (2 * j - 1 >= 0) acc.y = fma(w[2 * j - 1], p.x, acc.y);
+                if (2 * j <= 2 * RL) acc.y = fma(w[2 * j], p.y, acc.y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            v = acc;
+        }
+        if constexpr (RESID) {
+            v.x = dcur.x - v.x;
+            v.y = dcur.y - v.y;
+        }
+        *reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * lane) = v;
+    }
+}
+
+// FS consecutive steps starting at step `base` (base mod FS == 0), a workgroup barrier
+// before every even step: input rows travel in PAIRS (see the loader).
+template <int FS, int NW, bool LSF, bool RESID, int PH = 0>
+__device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, int yend,
+                                                long rowstride, int x, int wave, int lane,
+                                                const double *rows, double *myspec,
+                                                const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
+                                                const double (&w)[2 * LSF_RL + 1],
+                                                const double *__restrict__ data,
+                                                double *__restrict__ out, double2 (&ring)[FS],
+                                                double2 &dnext) {
+    if constexpr (PH < FS) {
+        const int i = base + PH;
+        if (i < nsteps) {
+            // (every LDS read of the previous pair has been consumed: data dependences)
+            if ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            conv_rows_step<FS, NW, LSF, RESID, PH>(i, y0, yend, rowstride, x, wave, lane, rows, myspec,
+                                                   q, w, data, out, ring, dnext);
+            // keep the steps apart: interleaving two of them costs more registers than the
+            // 128 that four wavefronts per SIMD allow
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        conv_rows_steps<FS, NW, LSF, RESID, PH + 1>(base, nsteps, y0, yend, rowstride, x, wave, lane,
+                                                    rows, myspec, q, w, data, out, ring, dnext);
+    }
+}
+
+template <int FS, int NW, bool LSF, bool LSYM, bool RESID, bool TSYM>
 __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                                                               const double *__restrict__ in,
-                                                              double *__restrict__ out) {
+                                                              double *__restrict__ out,
+                                                              const double *__restrict__ quad,
+                                                              const double *__restrict__ wl,
+                                                              const double *__restrict__ data) {
     constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, NC = NW + FS - 1, DP = CONV_DP;
     constexpr int NBUF = CONV_NBUF, RL = LSF_RL;
     extern __shared__ double smem[];
@@ -72,17 +221,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
     // strip, FS-1 common input columns) on one XCD and its L2 (bijective remap)
     int blk = blockIdx.x;
     if (A.xcd_remap) {
-        const int nb = gridDim.x, q = nb / 8, rm = nb % 8, xcd = blk % 8;
-        blk = (xcd < rm ? xcd * (q + 1) : rm * (q + 1) + (xcd - rm) * q) + blk / 8;
+        const int nb = gridDim.x, qq = nb / 8, rm = nb % 8, xcd = blk % 8;
+        blk = (xcd < rm ? xcd * (qq + 1) : rm * (qq + 1) + (xcd - rm) * qq) + blk / 8;
     }
     const int gy = blk / A.ngx, gx = blk - gy * A.ngx;
     const int x0 = gx * NW, y0 = gy * A.HY;
     const int yend = min(y0 + A.HY, A.H);
     const int nsteps = (yend - y0) + 2 * FHH;
+    const int npairs = (nsteps + 1) / 2;
     const long rowstride = (long)A.W * DP;
 
     if (wave == NW) {
-        // ---- loader wavefront ---------------------------------------------------
+        // ---- loader wavefront: input rows travel in pairs ---------------------------
+        // pair j = rows 2j, 2j+1 -> buffers (2j) % 4, (2j+1) % 4.  While the compute
+        // waves read pair j, pair j+1 is in flight (<= 2 NC = 50 loads outstanding,
+        // under the 63 a wavefront may have); its buffers held pair j-1, whose readers
+        // passed the barrier that precedes the issue.
         for (int c = 0; c < NC; ++c) {
             const int xx = x0 - FHH + c;
             if (xx < 0 || xx >= A.W)
@@ -90,142 +244,79 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                     *reinterpret_cast<double2 *>(rows + ((size_t)b * NC + c) * DP + 2 * lane) =
                         make_double2(0.0, 0.0);
         }
-        auto issue = [&](int i) -> bool {
+        auto issue = [&](int i) {
             const int r = y0 - FHH + i;
-            if (i >= nsteps || r < 0 || r >= A.H) return false;
+            if (i >= nsteps) return;
             double *dst = rows + (size_t)(i % NBUF) * NC * DP;
+            if (r < 0 || r >= A.H) {  // a row outside the cube is a row of zeros
+                for (int c = 0; c < NC; ++c)
+                    *reinterpret_cast<double2 *>(dst + (size_t)c * DP + 2 * lane) =
+                        make_double2(0.0, 0.0);
+                return;
+            }
             const double *src = in + (long)r * rowstride + 2 * lane;
+#if defined(D3D_CONV_DIAG) && D3D_CONV_DIAG == 1
+            return;  // diagnostic: no loads at all (compute floor)
+#endif
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 const int xx = x0 - FHH + c;
                 const bool ok = xx >= 0 && xx < A.W;
-                // always NC loads per row: the counted wait below relies on it
                 conv_glds16(src + (long)(ok ? xx : 0) * DP, ok ? dst + (size_t)c * DP : dummy);
             }
-            return true;
         };
         issue(0);
-        bool next_issued = issue(1);
+        issue(1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // zero slots written
-        for (int i = 0; i < nsteps; ++i) {
-            // row i has landed when at most row i+1's loads are outstanding
-            if (next_issued)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NC) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // B_i: row i is readable; the buffer of row i-1 is free again
-            asm volatile("s_barrier" ::: "memory");
-            next_issued = issue(i + 2);
+        for (int j = 0; j < npairs; ++j) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // pair j has landed
+            asm volatile("s_barrier" ::: "memory");           // readable; pair j-1's buffers free
+            issue(2 * j + 2);
+            issue(2 * j + 3);
         }
         return;
     }
 
     // ---- compute wavefront: output column x0 + wave --------------------------------
     const int x = x0 + wave;
-    const bool col_ok = x < A.W;
+    if (x >= A.W) {  // a column past the cube's edge: only keep the barriers company
+        asm volatile("s_barrier" ::: "memory");
+        for (int j = 0; j < npairs; ++j) asm volatile("s_barrier" ::: "memory");
+        return;
+    }
+    // taps and LSF weights: scalar registers for the whole march
+    double q[NQ][NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; ++a)
+#pragma unroll
+        for (int m = 0; m < NQ; ++m) q[a][m] = (TSYM && m > a) ? 0.0 : quad[a * NQ + m];
+    if constexpr (TSYM) {
+#pragma unroll
+        for (int a = 0; a < NQ; ++a)
+#pragma unroll
+            for (int m = a + 1; m < NQ; ++m) q[a][m] = q[m][a];
+    }
+    double w[2 * RL + 1];
+#pragma unroll
+    for (int j = 0; j <= 2 * RL; ++j) w[j] = 0.0;
+    if constexpr (LSF) {
+#pragma unroll
+        for (int j = 0; j <= 2 * RL; ++j) w[j] = (LSYM && j > RL) ? 0.0 : wl[j];
+        if constexpr (LSYM) {
+#pragma unroll
+            for (int j = RL + 1; j <= 2 * RL; ++j) w[j] = w[2 * RL - j];
+        }
+    }
     double2 ring[FS];
 #pragma unroll
     for (int k = 0; k < FS; ++k) ring[k] = make_double2(0.0, 0.0);
     double *myspec = spec + (size_t)wave * (DP + 2 * RL);
     double2 dnext = make_double2(0.0, 0.0);  // RESID: data of the row finished next
     asm volatile("s_barrier" ::: "memory");  // prologue
-    for (int sbase = 0; sbase < nsteps; sbase += FS) {
-#pragma unroll
-        for (int ph = 0; ph < FS; ++ph) {
-            const int i = sbase + ph;
-            if (i < nsteps) {
-                // every LDS read of the previous step has been consumed (data dependences)
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // B_i
-                const int r = y0 - FHH + i;
-                const int oy = r - FHH;  // the output row this step finishes
-                double2 dcur = dnext;
-                if constexpr (RESID) {
-                    // one step ahead: the data row of the output finished by step i+1
-                    const int oyn = oy + 1;
-                    if (col_ok && oyn >= y0 && oyn < yend)
-                        dnext = *reinterpret_cast<const double2 *>(A.data + (long)oyn * rowstride +
-                                                                   (long)x * DP + 2 * lane);
-                }
-                if (col_ok && r >= 0 && r < A.H) {
-                    const double *rb = rows + ((size_t)(i % NBUF) * NC + wave) * DP + 2 * lane;
-                    double2 P[NQ];
-#pragma unroll
-                    for (int m = 0; m < FHH; ++m) {
-                        const double2 lo = *reinterpret_cast<const double2 *>(rb + (size_t)m * DP);
-                        const double2 hi =
-                            *reinterpret_cast<const double2 *>(rb + (size_t)(FS - 1 - m) * DP);
-                        P[m].x = lo.x + hi.x;
-                        P[m].y = lo.y + hi.y;
-                    }
-                    P[FHH] = *reinterpret_cast<const double2 *>(rb + (size_t)FHH * DP);
-#pragma unroll
-                    for (int a = 0; a <= FHH; ++a) {
-                        const int ylo = r - a, yhi = r + a;  // output rows of slots FHH-a, FHH+a
-                        const bool lo_ok = ylo >= y0 && ylo < yend;
-                        const bool hi_ok = a > 0 && yhi >= y0 && yhi < yend;
-                        if (lo_ok || hi_ok) {
-                            double2 T;
-                            {
-                                const double q0 = A.quad[a * NQ];
-                                T.x = q0 * P[0].x;
-                                T.y = q0 * P[0].y;
-                            }
-#pragma unroll
-                            for (int m = 1; m < NQ; ++m) {
-                                const double q = A.quad[a * NQ + m];
-                                T.x = fma(q, P[m].x, T.x);
-                                T.y = fma(q, P[m].y, T.y);
-                            }
-                            if (lo_ok) {
-                                ring[(ph + FHH - a) % FS].x += T.x;
-                                ring[(ph + FHH - a) % FS].y += T.y;
-                            }
-                            if (hi_ok) {
-                                ring[(ph + FHH + a) % FS].x += T.x;
-                                ring[(ph + FHH + a) % FS].y += T.y;
-                            }
-                        }
-                    }
-                }
-                if (col_ok && oy >= y0 && oy < yend) {
-                    double2 v = ring[ph % FS];
-                    if constexpr (LSF) {
-                        // LSF on the finished row: spectrum -> wave-private LDS buffer with a
-                        // circular halo of RL channels -> aligned 16-byte window reads
-                        *reinterpret_cast<double2 *>(myspec + RL + 2 * lane) = v;
-                        if (2 * lane < RL)
-                            *reinterpret_cast<double2 *>(myspec + DP + RL + 2 * lane) = v;
-                        if (2 * lane >= DP - RL)
-                            *reinterpret_cast<double2 *>(myspec + RL + 2 * lane - DP) = v;
-                        __builtin_amdgcn_wave_barrier();  // LDS is in order per wavefront
-                        const double *bt = myspec + 2 * lane;
-                        double2 acc = make_double2(0.0, 0.0);
-#pragma unroll
-                        for (int j = 0; j < RL + 1; ++j) {
-                            const double2 p = *reinterpret_cast<const double2 *>(bt + 2 * j);
-                            // p = (w[2j], w[2j+1]); acc.x = sum wl[k] w[k], acc.y = sum wl[k] w[k+1]
-                            auto wgt = [&](int k) -> double {
-                                return A.wl[LSYM && k > RL ? 2 * RL - k : k];
-                            };
-                            if (2 * j <= 2 * RL) acc.x = fma(wgt(2 * j), p.x, acc.x);
-                            if (2 * j + 1 <= 2 * RL) acc.x = fma(wgt(2 * j + 1), p.y, acc.x);
-                            if (2 * j - 1 >= 0) acc.y = fma(wgt(2 * j - 1), p.x, acc.y);
-                            if (2 * j <= 2 * RL) acc.y = fma(wgt(2 * j), p.y, acc.y);
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                        v = acc;
-                    }
-                    if constexpr (RESID) {
-                        v.x = dcur.x - v.x;
-                        v.y = dcur.y - v.y;
-                    }
-                    *reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP +
-                                                 2 * lane) = v;
-                }
-                ring[ph % FS] = make_double2(0.0, 0.0);
-            }
-        }
-    }
+    // blocks of FS steps (the ring rotates through static registers)
+    for (int base = 0; base < nsteps; base += FS)
+        conv_rows_steps<FS, NW, LSF, RESID>(base, nsteps, y0, yend, rowstride, x, wave, lane, rows,
+                                            myspec, q, w, data, out, ring, dnext);
 }
 
 }  // namespace d3d
