@@ -454,8 +454,9 @@ def main():
     for _ in range(args.conv_iters):
         eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
     slots_ms = eng.timer_stop() / max(args.conv_iters, 1)
-    roofline_conv = conv_entry(slots_ms, "k_spectral_dense + k_spatial_march (slot layout)",
-                               "k_spatial_march")
+    roofline_conv = conv_entry(slots_ms, "k_conv_rows (LSF x FSF in one pass, slot layout)",
+                               "k_conv_rows")
+    roofline_conv["algorithmic_bytes"] = conv_bytes
     roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
                                           "k_spatial_z")
 

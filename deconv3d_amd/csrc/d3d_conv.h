@@ -171,7 +171,13 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
             v.x = dcur.x - v.x;
             v.y = dcur.y - v.y;
         }
-        *reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * lane) = v;
+        double2 *dst = reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * lane);
+#if defined(D3D_CONV_NT)
+        __builtin_nontemporal_store(v.x, &dst->x);
+        __builtin_nontemporal_store(v.y, &dst->y);
+#else
+        *dst = v;
+#endif
     }
 }
 
@@ -265,6 +271,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                 conv_glds16(src + (long)(ok ? xx : 0) * DP, ok ? dst + (size_t)c * DP : dummy);
             }
         };
+        __builtin_amdgcn_s_setprio(3);  // the loads are on everybody's critical path (-1 us)
         issue(0);
         issue(1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // zero slots written
