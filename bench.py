@@ -484,6 +484,23 @@ def main():
         "roofline_conv_ref_layout": roofline_conv_ref_layout,
     }
 
+    if rank == 0 and not args.no_extras:
+        # PCIe-inclusive: the same sweeps with EVERY sweep streamed to a host chain
+        # (keep_one_in = 1: parameters + log ratios, 2.9 MB per sweep) -- device snapshot,
+        # copy stream, pinned buffers: the compute stream does not wait for the host
+        ks = max(2, min(args.steps, 10))
+        chain = np.empty((sweep + ks + 1, H, W, 3))
+        dlog = np.empty((sweep + ks + 1, H, W))
+        eng.sync()
+        t1 = time.perf_counter()
+        eng.mh_sweeps(ks, sweep, 1, chain, dlog)
+        eng.sync()
+        out["chain_streaming"] = {
+            "keep_one_in": 1, "ms_per_step": round((time.perf_counter() - t1) * 1e3 / ks, 4),
+            "bytes_per_step": int(H * W * 4 * 8),
+            "note": "same kernel path as `value`, every sweep copied to the host chain"}
+        sweep += ks
+        del chain, dlog
     if rank == 0:
         out["host"] = host_info()
     if rank == 0 and not args.no_extras and args.workload == "c3_300x300x128":

@@ -133,6 +133,16 @@ struct d3d_ctx {
     std::vector<std::vector<HaloEntry>> plans;
     double *halo_send = nullptr, *halo_recv = nullptr;
     size_t halo_send_cap = 0, halo_recv_cap = 0;
+    // asynchronous chain streaming (lib/run.py:447-451 chain[i] = parameters, :428-432):
+    // at a saved sweep the compute stream snapshots parameters + log ratios device to
+    // device (microseconds), a COPY stream moves the snapshot to a pinned host buffer,
+    // and the host thread copies it into the caller's (pageable) chain while the GPU
+    // runs on -- STREAM_NB snapshots may be in flight
+    static constexpr int STREAM_NB = 4;
+    hipStream_t copy_stream = nullptr;
+    double *snap_dev[STREAM_NB] = {};   // [HW*4]: params (HW*3) | dlog (HW)
+    double *snap_host[STREAM_NB] = {};  // pinned
+    hipEvent_t snap_ready[STREAM_NB] = {}, snap_done[STREAM_NB] = {};
     // RCCL communicator of the tiled chain (d3d_comm_init)
     ncclComm_t comm = nullptr;
     int comm_rank = -1, comm_size = 0;
@@ -188,6 +198,7 @@ struct d3d_ctx {
     bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
     bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
     double *fsf_quad = nullptr;   // [(fhh+1)^2] quadrant taps of an x/y-symmetric square FSF (k_conv_rows)
+    double *fsf_quad_sep = nullptr;  // the same table for an outer-product FSF: row 0 = v, row 1 = u
     bool fsf_symt = false;        // ... and fsf[k][i] == fsf[i][k] bit for bit (radial FSFs)
     bool lsf_dense_sym = false;   // dense LSF weights mirror-symmetric bit for bit
     int conv_rows = 1;            // D3D_CONV_ROWS=0: never use the one-pass kernel k_conv_rows
@@ -579,7 +590,7 @@ bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     }
 }
 
-template <int FS, bool LSF, bool LSYM, bool RESID, bool TSYM>
+template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM>
 int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
     constexpr int NW = 15;
     d3d::ConvRowsArgs A;
@@ -607,12 +618,13 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
-                       in, out, (const double *)c->fsf_quad, (const double *)c->lsf_dense, data);
+                       in, out, (const double *)(TSYM == 2 ? c->fsf_quad_sep : c->fsf_quad),
+                       (const double *)c->lsf_dense, data);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-template <int FS, bool TSYM>
+template <int FS, int TSYM>
 int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
     const bool sym = c->lsf_dense_sym;
     if (lsf) {
@@ -627,8 +639,9 @@ int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double 
 
 template <int FS>
 int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    if (c->fsf_symt) return launch_conv_rows_ts<FS, true>(c, in, out, data, lsf);
-    return launch_conv_rows_ts<FS, false>(c, in, out, data, lsf);
+    if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2>(c, in, out, data, lsf);
+    if (c->fsf_symt) return launch_conv_rows_ts<FS, 1>(c, in, out, data, lsf);
+    return launch_conv_rows_ts<FS, 0>(c, in, out, data, lsf);
 }
 
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
@@ -644,7 +657,8 @@ int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *da
 
 // True when the spatial pass can apply the LSF itself (fused epilogue).
 bool can_fuse_lsf(const d3d_ctx *c) {
-    if (conv_rows_usable(c, true)) return true;
+    // (an outer-product FSF honours D3D_SEP_FUSE=0: LSF in its own pass, for A/B tests)
+    if (conv_rows_usable(c, true) && !(c->fsf_sep && c->march_mode > 0 && !c->sep_fuse)) return true;
     if (!c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
     const bool sep = c->fsf_sep && c->sep_fuse;  // k_spatial_sep_lsf
 #ifndef D3D_EXPERIMENTS
@@ -664,9 +678,7 @@ bool can_fuse_lsf(const d3d_ctx *c) {
 // fuse_lsf: also apply the LSF along z (only when can_fuse_lsf()).
 int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
                    bool fuse_lsf = false) {
-    // an outer-product FSF keeps its own one-pass kernel (2*FS instead of (FHH+1)^2 FMAs)
-    const bool sep_path = c->fsf_sep && c->march_mode > 0 && (!fuse_lsf || c->sep_fuse);
-    if (!sep_path && conv_rows_usable(c, fuse_lsf)) return launch_conv_rows(c, in, out, data, fuse_lsf);
+    if (conv_rows_usable(c, fuse_lsf)) return launch_conv_rows(c, in, out, data, fuse_lsf);
     int nt = pick_nt(c->HL);
     if (const char *e = getenv("D3D_SPATIAL_NT")) {
         const int v = atoi(e);
@@ -1225,6 +1237,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     CTX_TRY(hipMalloc(&c->fsf, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->sep_uv, (size_t)(fh + fw) * sizeof(double)));
     CTX_TRY(hipMalloc(&c->fsf_quad, (size_t)fh * fw * sizeof(double)));
+    CTX_TRY(hipMalloc(&c->fsf_quad_sep, (size_t)fh * fw * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_shift, (size_t)c->N * sizeof(int)));
     CTX_TRY(hipMalloc(&c->lsf_weight, (size_t)c->N * sizeof(double)));
     CTX_TRY(hipMalloc(&c->lsf_dense, (2 * d3d::LSF_RL + 1) * sizeof(double)));
@@ -1279,6 +1292,13 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
     c->comm = nullptr;
+    for (int b = 0; b < d3d_ctx::STREAM_NB; ++b) {
+        if (c->snap_dev[b]) (void)hipFree(c->snap_dev[b]);
+        if (c->snap_host[b]) (void)hipHostFree(c->snap_host[b]);
+        if (c->snap_ready[b]) (void)hipEventDestroy(c->snap_ready[b]);
+        if (c->snap_done[b]) (void)hipEventDestroy(c->snap_done[b]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->halo_send) (void)hipFree(c->halo_send);
     if (c->halo_recv) (void)hipFree(c->halo_recv);
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
@@ -1286,7 +1306,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
-                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad};
+                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -1387,6 +1407,17 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
             }
         HIP_TRY(hipMemcpyAsync(c->fsf_quad, quad.data(), quad.size() * sizeof(double),
                                hipMemcpyHostToDevice, c->stream));
+        if (c->fsf_sep) {
+            // fsf = u v^T (u = centre column / centre tap, v = centre row, as sep_uv):
+            // row 0 = v by distance from the centre, row 1 = u
+            std::vector<double> qs((size_t)nq * nq, 0.0);
+            const double cc = fsf[fhh * c->fw + fhh];
+            for (int e = 0; e < nq; ++e) qs[e] = fsf[fhh * c->fw + (fhh - e)];
+            for (int a = 0; a < nq; ++a) qs[(size_t)nq + a] = fsf[(fhh - a) * c->fw + fhh] / cc;
+            HIP_TRY(hipMemcpyAsync(c->fsf_quad_sep, qs.data(), qs.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     if (const char *e = getenv("D3D_CONV_ROWS")) c->conv_rows = atoi(e);
@@ -1805,6 +1836,59 @@ int d3d_window_stats(d3d_ctx *c, int y, int x, const double p_new[3], double out
 
 namespace {
 
+// ---- asynchronous chain streaming ------------------------------------------------
+struct SnapQueue {
+    int slot[d3d_ctx::STREAM_NB];  // chain slot each in-flight buffer belongs to
+    int head = 0, count = 0;       // ring of in-flight buffers, oldest first
+};
+
+int snap_setup(d3d_ctx *c) {
+    if (c->copy_stream) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    const size_t bytes = (size_t)c->HW * 4 * sizeof(double);
+    for (int b = 0; b < d3d_ctx::STREAM_NB; ++b) {
+        HIP_TRY(hipMalloc(&c->snap_dev[b], bytes));
+        HIP_TRY(hipHostMalloc((void **)&c->snap_host[b], bytes, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&c->snap_ready[b], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->snap_done[b], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+// The oldest snapshot in flight: wait for its copy, hand it to the caller's arrays.
+int snap_drain_one(d3d_ctx *c, SnapQueue &q, double *chain_out, double *dlog_out) {
+    const int b = q.head;
+    HIP_TRY(hipEventSynchronize(c->snap_done[b]));
+    const size_t slot = (size_t)q.slot[b];
+    if (chain_out)
+        memcpy(chain_out + slot * c->HW * 3, c->snap_host[b], (size_t)c->HW * 3 * sizeof(double));
+    if (dlog_out)
+        memcpy(dlog_out + slot * c->HW, c->snap_host[b] + (size_t)c->HW * 3,
+               (size_t)c->HW * sizeof(double));
+    q.head = (q.head + 1) % d3d_ctx::STREAM_NB;
+    --q.count;
+    return 0;
+}
+
+// Snapshot the current parameters / log ratios for chain slot `slot`.
+int snap_push(d3d_ctx *c, SnapQueue &q, int slot, double *chain_out, double *dlog_out) {
+    if (q.count == d3d_ctx::STREAM_NB)
+        if (int rc = snap_drain_one(c, q, chain_out, dlog_out)) return rc;
+    const int b = (q.head + q.count) % d3d_ctx::STREAM_NB;
+    HIP_TRY(hipMemcpyAsync(c->snap_dev[b], c->params, (size_t)c->HW * 3 * sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->snap_dev[b] + (size_t)c->HW * 3, c->dlog, (size_t)c->HW * sizeof(double),
+                           hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->snap_ready[b], c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->snap_ready[b], 0));
+    HIP_TRY(hipMemcpyAsync(c->snap_host[b], c->snap_dev[b], (size_t)c->HW * 4 * sizeof(double),
+                           hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipEventRecord(c->snap_done[b], c->copy_stream));
+    q.slot[b] = slot;
+    ++q.count;
+    return 0;
+}
+
 // Every colour class of one part, for one sweep (lib/run.py:367-519 restricted to
 // the part, in colour order).
 int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
@@ -1890,6 +1974,9 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
         if (rc) return rc;
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
+    SnapQueue snaps;
+    if (chain_out || dlog_out)
+        if (int rc = snap_setup(c)) return rc;
     // k_mh_flow addresses SLOT_ERR through a raw buffer (32-bit byte offsets)
     const bool flow = c->mh_flow && c->mh_defer == 1 && !c->tiled && c->parts.size() == 1 &&
                       c->Dp <= 256 && c->flow_K > 0 &&
@@ -1911,16 +1998,11 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                 }
             }
         }
-        if (s % keep_one_in == 0) {  // lib/run.py:353, 430-432, 449-451
-            const size_t slot = (size_t)(s / keep_one_in);
-            if (chain_out)
-                HIP_TRY(hipMemcpyAsync(chain_out + slot * c->HW * 3, c->params,
-                                       (size_t)c->HW * 3 * sizeof(double), hipMemcpyDeviceToHost,
-                                       c->stream));
-            if (dlog_out)
-                HIP_TRY(hipMemcpyAsync(dlog_out + slot * c->HW, c->dlog,
-                                       (size_t)c->HW * sizeof(double), hipMemcpyDeviceToHost,
-                                       c->stream));
+        if (s % keep_one_in == 0 && (chain_out || dlog_out)) {
+            // lib/run.py:353, 430-432, 449-451 -- streamed: the compute stream only pays
+            // for a device-to-device snapshot
+            int rc = snap_push(c, snaps, s / keep_one_in, chain_out, dlog_out);
+            if (rc) return rc;
         }
         // lib/run.py:521-534: squash the error creep with a fresh residual.  A tile
         // first gathers the parameters of the spaxels of its frame from their owners.
@@ -1940,6 +2022,8 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     if (flow)
         HIP_TRY(hipMemcpyAsync(&flow_err, c->flow_err, sizeof flow_err, hipMemcpyDeviceToHost,
                                c->stream));
+    while (snaps.count > 0)
+        if (int rc = snap_drain_one(c, snaps, chain_out, dlog_out)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (accepted) *accepted = (int64_t)acc;
     NEED(!flow_err, D3D_ERR_HIP, "k_mh_flow: a dependency wait timed out; the chain state is invalid");
@@ -2342,7 +2426,14 @@ int d3d_halo_plan(d3d_ctx *c, int plan, int n, const int *entries) {
     c->plans[plan] = v;
     HIP_TRY(hipStreamSynchronize(c->stream));  // nobody may still use the old buffers
     if (so > c->halo_send_cap) {
-        if (c->halo_send) (void)hipFree(c->halo_send);
+        for (int b = 0; b < d3d_ctx::STREAM_NB; ++b) {
+        if (c->snap_dev[b]) (void)hipFree(c->snap_dev[b]);
+        if (c->snap_host[b]) (void)hipHostFree(c->snap_host[b]);
+        if (c->snap_ready[b]) (void)hipEventDestroy(c->snap_ready[b]);
+        if (c->snap_done[b]) (void)hipEventDestroy(c->snap_done[b]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->halo_send) (void)hipFree(c->halo_send);
         c->halo_send = nullptr;
         c->halo_send_cap = 0;
         HIP_TRY(hipMalloc(&c->halo_send, so * sizeof(double)));

@@ -42,7 +42,8 @@ struct ConvRowsArgs {
 // whole march (v_fma_f64 takes one scalar operand).  Through a struct member they were
 // re-fetched with vector global loads in every step, each a full memory latency on the
 // critical path (measured: 107 us per cube instead of 5x).
-//   quad  [(FHH+1)^2] quadrant taps by distance from the centre tap,
+//   quad  [(FHH+1)^2] quadrant taps by distance from the centre tap (outer-product FSFs:
+//         row 0 = v[e], row 1 = u[a] with fsf[FHH-a][FHH-e] = u[a] v[e]),
 //         quad[a*(FHH+1)+e] = fsf[FHH-a][FHH-e]; TSYM: the FSF is also symmetric under
 //         transposition (quad[a][e] == quad[e][a]: every radial FSF), only e <= a is read
 //   wl    dense LSF weights [2*LSF_RL+1] (LSF); LSYM: mirror-symmetric, first RL+1 read
@@ -74,7 +75,7 @@ __device__ __forceinline__ void conv_glds16(const double *gsrc, double *lds_dst)
 // when tap rows FHH-a / FHH+a reach an output row of the strip at all: that skips the
 // dot products of the first and last FHH steps (10 % of a strip's FMAs) for one scalar
 // bit test each.
-template <int FS, int NW, bool LSF, bool RESID, int PH>
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH>
 __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long rowstride, int x,
                                                int wave, int lane, const double *rows,
                                                double *myspec,
@@ -113,10 +114,35 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
             P[e].x = lo.x + hi.x;
             P[e].y = lo.y + hi.y;
         }
-#if defined(D3D_CONV_DIAG) && D3D_CONV_DIAG == 2
-        ring[PH % FS].x += P[0].x + P[1].x + P[2].x + P[FHH].x;  // diagnostic: no stencil math
-        ring[PH % FS].y += P[0].y + P[1].y + P[2].y + P[FHH].y;
-#else
+        if constexpr (SEP) {
+            // outer-product FSF, fsf[k][m] = u[k] v[m] (every Gaussian with pa = 0): reduce the
+            // row along x once, X = sum_e v[e] P[e], and feed the slots with u[a] X --
+            // 2 (FHH+1) + FS FMAs per output instead of (FHH+1)^2 + FS.  q[0][e] = v, q[1][a] = u.
+            double2 X;
+            X.x = q[0][0] * P[0].x;
+            X.y = q[0][0] * P[0].y;
+#pragma unroll
+            for (int e = 1; e < NQ; ++e) {
+                X.x = fma(q[0][e], P[e].x, X.x);
+                X.y = fma(q[0][e], P[e].y, X.y);
+            }
+#pragma unroll
+            for (int a = 0; a <= FHH; ++a) {
+                if (!((need >> a) & 1u)) {
+                    if (a == FHH) ring[(PH + 2 * FHH) % FS] = make_double2(0.0, 0.0);
+                    continue;
+                }
+                ring[(PH + FHH - a) % FS].x = fma(q[1][a], X.x, ring[(PH + FHH - a) % FS].x);
+                ring[(PH + FHH - a) % FS].y = fma(q[1][a], X.y, ring[(PH + FHH - a) % FS].y);
+                if (a == FHH) {
+                    ring[(PH + 2 * FHH) % FS].x = q[1][a] * X.x;
+                    ring[(PH + 2 * FHH) % FS].y = q[1][a] * X.y;
+                } else if (a > 0) {
+                    ring[(PH + FHH + a) % FS].x = fma(q[1][a], X.x, ring[(PH + FHH + a) % FS].x);
+                    ring[(PH + FHH + a) % FS].y = fma(q[1][a], X.y, ring[(PH + FHH + a) % FS].y);
+                }
+            }
+        } else {
 #pragma unroll
         for (int a = 0; a <= FHH; ++a) {
             // tap rows FHH-a and FHH+a are equal: one dot product for the two output rows
@@ -142,7 +168,7 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
                 ring[(PH + FHH + a) % FS].y += T.y;
             }
         }
-#endif
+        }
     }
     if (store) {
         double2 v = ring[PH % FS];
@@ -183,7 +209,7 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
 
 // FS consecutive steps starting at step `base` (base mod FS == 0), a workgroup barrier
 // before every even step: input rows travel in PAIRS (see the loader).
-template <int FS, int NW, bool LSF, bool RESID, int PH = 0>
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH = 0>
 __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, int yend,
                                                 long rowstride, int x, int wave, int lane,
                                                 const double *rows, double *myspec,
@@ -197,18 +223,20 @@ __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, in
         if (i < nsteps) {
             // (every LDS read of the previous pair has been consumed: data dependences)
             if ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            conv_rows_step<FS, NW, LSF, RESID, PH>(i, y0, yend, rowstride, x, wave, lane, rows, myspec,
-                                                   q, w, data, out, ring, dnext);
+            conv_rows_step<FS, NW, LSF, RESID, SEP, PH>(i, y0, yend, rowstride, x, wave, lane, rows,
+                                                        myspec, q, w, data, out, ring, dnext);
             // keep the steps apart: interleaving two of them costs more registers than the
             // 128 that four wavefronts per SIMD allow
             __builtin_amdgcn_sched_barrier(0);
         }
-        conv_rows_steps<FS, NW, LSF, RESID, PH + 1>(base, nsteps, y0, yend, rowstride, x, wave, lane,
-                                                    rows, myspec, q, w, data, out, ring, dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, SEP, PH + 1>(base, nsteps, y0, yend, rowstride, x, wave,
+                                                         lane, rows, myspec, q, w, data, out, ring,
+                                                         dnext);
     }
 }
 
-template <int FS, int NW, bool LSF, bool LSYM, bool RESID, bool TSYM>
+// TSYM = 2 selects the outer-product form (SEP): quad holds v[e] (row 0) and u[a] (row 1).
+template <int FS, int NW, bool LSF, bool LSYM, bool RESID, int TSYM>
 __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                                                               const double *__restrict__ in,
                                                               double *__restrict__ out,
@@ -296,8 +324,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
 #pragma unroll
     for (int a = 0; a < NQ; ++a)
 #pragma unroll
-        for (int m = 0; m < NQ; ++m) q[a][m] = (TSYM && m > a) ? 0.0 : quad[a * NQ + m];
-    if constexpr (TSYM) {
+        for (int m = 0; m < NQ; ++m)
+            q[a][m] = ((TSYM == 1 && m > a) || (TSYM == 2 && a > 1)) ? 0.0 : quad[a * NQ + m];
+    if constexpr (TSYM == 1) {
 #pragma unroll
         for (int a = 0; a < NQ; ++a)
 #pragma unroll
@@ -322,8 +351,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
     asm volatile("s_barrier" ::: "memory");  // prologue
     // blocks of FS steps (the ring rotates through static registers)
     for (int base = 0; base < nsteps; base += FS)
-        conv_rows_steps<FS, NW, LSF, RESID>(base, nsteps, y0, yend, rowstride, x, wave, lane, rows,
-                                            myspec, q, w, data, out, ring, dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, TSYM == 2>(base, nsteps, y0, yend, rowstride, x, wave, lane,
+                                                       rows, myspec, q, w, data, out, ring, dnext);
 }
 
 }  // namespace d3d

@@ -281,3 +281,41 @@ def test_resume_continues_the_random_streams(tmp_path):
     replay = d3d.Run(cube, inst, max_iterations=7, initial_parameters=name + "_parameters.npy",
                      **kw)
     assert not np.allclose(replay.chain[-1], whole.chain[-1], rtol=1e-3, atol=1e-3)
+
+
+def test_streamed_chain_equals_the_synchronous_one():
+    """d3d_mh_sweeps streams saved sweeps through device snapshots, a copy stream and
+    pinned buffers (more saved sweeps than buffers, so they are recycled): the chain
+    and the log ratios it delivers equal what stopping after every sweep and reading
+    the state back gives (lib/run.py:428-432, 447-451)."""
+    from oracle import deconv3d_oracle as O
+    D, H, W = 16, 11, 13
+    fsf, lsf = O.gaussian_fsf_image(2.0), O.gaussian_lsf_vector(D, 0.7)
+    data, var, mask, truth, init, mn, mx = O.synthetic_case(D, H, W, fsf, lsf, seed=3)
+    n = 23
+
+    def engine():
+        e = _lib.Engine((D, H, W), fsf.shape)
+        e.set_taps(fsf, lsf)
+        e.set_data(data, var, mask=mask)
+        e.set_params(init)
+        e.mh_config(mn, mx, 0.1, float(mx[0] ** 2), seed=5, refresh_every=7)
+        return e
+    for keep in (1, 3):
+        slots = n // keep + 1
+        chain = np.full((slots, H, W, 3), np.nan)
+        dlog = np.full((slots, H, W), np.nan)
+        with engine() as e:
+            acc = e.mh_sweeps(n, 1, keep, chain, dlog)
+        want_chain = np.full_like(chain, np.nan)
+        want_dlog = np.full_like(dlog, np.nan)
+        total = 0
+        with engine() as e:
+            for s in range(1, n + 1):
+                total += e.mh_sweeps(1, s)
+                if s % keep == 0:
+                    want_chain[s // keep] = e.get_params()
+                    want_dlog[s // keep] = e.get_dlog()
+        np.testing.assert_array_equal(chain, want_chain)
+        np.testing.assert_array_equal(dlog, want_dlog)
+        assert acc == total
