@@ -177,6 +177,13 @@ struct d3d_ctx {
                                   // slower than one k_mh_ws launch per colour: DESIGN.md)
     int flow_K = 0, flow_LY = 0, flow_LX = 0, flow_items = 0, flow_grid = 0;
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
+    // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
+    // monotonic ticket counter, so that nothing needs clearing between launches
+    int mh_pair = 1;               // D3D_MH_PAIR=0: one launch per colour class
+    unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item
+    unsigned pair_epoch = 0, pair_tickets = 0;
+    std::vector<int> flow_first;   // first item of every active colour (+ total)
+    std::vector<int> flow_colour;  // colour class index of every active colour
     int4 *flow_ent = nullptr;     // [items] {y, x, real, colour ordinal}
     int4 *flow_col = nullptr;     // [K] {first ticket, cy, cx, -}
     int *flow_lat = nullptr;      // [K][LY*LX]
@@ -913,6 +920,64 @@ int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
     return 0;
 }
 
+// Colours ka (N: one layer pending, nothing written) and ka+1 (W) of the active-colour
+// list in ONE launch (k_mh_pair).  P carries the one pending layer.
+template <bool UV, int U, int K>
+int launch_mh_pair_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHPair &F, uint32_t sweep) {
+    constexpr int NS = 256;
+    size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, 2) * sizeof(double);
+    lds += 16;  // the ticket
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_pair<NS, UV, U, K>), dim3((unsigned)(F.n_a + F.n_b)),
+                       dim3(NS + 64), lds, c->stream, P, F, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    d3d::MHPair F;
+    F.ent = c->flow_ent;
+    F.lat = c->flow_lat;
+    F.ctl = c->pair_state;
+    F.done = c->pair_state + 4;
+    F.err = c->flow_err;
+    F.first_a = c->flow_first[ka];
+    F.n_a = c->flow_first[ka + 1] - c->flow_first[ka];
+    F.first_b = c->flow_first[ka + 1];
+    F.n_b = c->flow_first[ka + 2] - c->flow_first[ka + 1];
+    F.ka = ka;
+    F.a_cy = c->flow_colour[ka] / c->fw;
+    F.a_cx = c->flow_colour[ka] % c->fw;
+    F.LY = c->flow_LY;
+    F.LX = c->flow_LX;
+    F.ticket_base = c->pair_tickets;
+    F.epoch = ++c->pair_epoch;
+    const int ga = pend_free_buf(c);
+    int gb = 0;
+    for (int b = 0; b < 4; ++b) {
+        bool used = b == ga;
+        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
+        if (!used) gb = b;
+    }
+    F.G_a = c->gbuf[ga];
+    F.G_b = c->gbuf[gb];
+    c->pair_tickets += (unsigned)(F.n_a + F.n_b);
+    const bool uv = c->ivar_is_uniform && c->uniform_fast_path;
+    int rc;
+    if (c->Dp > 160)
+        rc = uv ? launch_mh_pair_t<true, 4, 4>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 4>(c, P, F, sweep);
+    else
+        rc = uv ? launch_mh_pair_t<true, 4, 2>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 2>(c, P, F, sweep);
+    if (rc) return rc;
+    // afterwards colour B's updates are the only pending layer (local residues == colour
+    // indices: an unpartitioned, untiled context)
+    c->lay_n = 0;
+    pend_push(c, c->flow_colour[ka + 1] / c->fw, c->flow_colour[ka + 1] % c->fw, gb);
+    c->pend_part = 0;
+    return 0;
+}
+
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
     // tail, so D <= 256) + one prepare wavefront
@@ -982,6 +1047,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
+    if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
     // other MH kernels keep one layer
@@ -1108,6 +1174,13 @@ int build_colour_lists(d3d_ctx *c) {
         }
         c->flow_K = (int)cols.size();
         c->flow_items = (int)ents.size();
+        c->flow_first.clear();
+        c->flow_colour.clear();
+        for (const int4 &cc : cols) {
+            c->flow_first.push_back(cc.x);
+            c->flow_colour.push_back(cc.y * c->fw + cc.z);
+        }
+        c->flow_first.push_back(c->flow_items);
         if (c->flow_K > 0) {
             HIP_TRY(hipMemcpyAsync(c->flow_ent, ents.data(), ents.size() * sizeof(int4),
                                    hipMemcpyHostToDevice, c->stream));
@@ -1270,6 +1343,8 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
         CTX_TRY(hipMalloc(&c->flow_lat, ncol * c->flow_LY * c->flow_LX * sizeof(int)));
         c->flow_state_bytes = ((4 + ncol + c->spx_cap) * sizeof(unsigned) + 15) / 16 * 16;
         CTX_TRY(hipMalloc(&c->flow_state, c->flow_state_bytes));
+        CTX_TRY(hipMalloc(&c->pair_state, (4 + c->spx_cap) * sizeof(unsigned)));
+        CTX_TRY(hipMemsetAsync(c->pair_state, 0, (4 + c->spx_cap) * sizeof(unsigned), c->stream));
         CTX_TRY(hipMalloc(&c->flow_err, 16));
         CTX_TRY(hipMemsetAsync(c->flow_err, 0, 16, c->stream));
         int cus = 0;
@@ -1305,7 +1380,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
-                    c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->sep_uv,
+                    c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->pair_state, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1900,10 +1975,31 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
     if (c->lay_n && (c->pend_part != pi || !deferred))
         if (int rc = flush_pending(c)) return rc;
+    // two colour classes per launch (k_mh_pair) where the N/W alternation of two pending
+    // layers allows it: an unpartitioned context, a launch that fills the chip
+    const bool pairs = deferred && c->mh_pair && !partitioned && c->mh_defer == 1 && c->Dp <= 256 &&
+                       pt.layers == 2 && c->flow_K > 1 && !c->flow_first.empty();
+    int ord = 0;  // ordinal of `col` among the active colours
     for (int col = 0; col < ncol; ++col) {
         const int n_real = pt.real[col];
         if (n_real <= 0) continue;
+        const int ka = ord++;
         if (deferred) c->pend_part = pi;  // fill_mh_args takes the domain from it
+        if (pairs && c->lay_n == 1 && ka + 1 < c->flow_K) {
+#ifdef D3D_EXPERIMENTS
+            if (c->stampbuf) goto single;  // phase stamps are per colour launch
+#endif
+            int rc = launch_mh_pair(c, ka, sweep);
+            if (rc) return rc;
+            // skip colour B in this loop
+            ++col;
+            while (col < ncol && pt.real[col] <= 0) ++col;
+            ++ord;
+            continue;
+        }
+#ifdef D3D_EXPERIMENTS
+    single:
+#endif
         d3d::MHArgs P;
         fill_mh_args(c, P);
         P.spx = c->spx + pt.off[col];
@@ -2019,14 +2115,15 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     unsigned long long acc = 0;
     unsigned flow_err = 0;
     HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
-    if (flow)
+    if (flow || c->mh_pair)
         HIP_TRY(hipMemcpyAsync(&flow_err, c->flow_err, sizeof flow_err, hipMemcpyDeviceToHost,
                                c->stream));
     while (snaps.count > 0)
         if (int rc = snap_drain_one(c, snaps, chain_out, dlog_out)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (accepted) *accepted = (int64_t)acc;
-    NEED(!flow_err, D3D_ERR_HIP, "k_mh_flow: a dependency wait timed out; the chain state is invalid");
+    NEED(!flow_err, D3D_ERR_HIP,
+         "k_mh_flow / k_mh_pair: a dependency wait timed out; the chain state is invalid");
     return D3D_OK;
 }
 

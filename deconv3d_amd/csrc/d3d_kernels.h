@@ -2252,7 +2252,9 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
 // workgroup inside the launch: write-through (sc1) stores and sc1 loads for
 // every such byte, so that neither a release nor an acquire fence is needed
 // (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
-template <int NS, bool UV, bool COH, int U, int M>
+// COHG: only the G row this item leaves is published coherently (k_mh_pair: the other
+// colour class of the same launch reads it; the residual is handed over by nobody).
+template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                           uint32_t sweep, long stamp_at) {
     constexpr int ROW = 1 + M;
@@ -2370,7 +2372,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     }
     D3D_MH_STAMP(stamp_at, 2, 0);
     if (!real) {
-        mh_ws_zero_row<COH>(P, I);
+        mh_ws_zero_row<COHG>(P, I);
         return;
     }
     __syncthreads();  // group partial sums are in S.red, the lines in S.G / sEN
@@ -2387,7 +2389,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs)) return;
     if (tid < Dp) {
         double *dst = I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * Dp + tid;
-        if (COH)
+        if (COHG)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst),
                                (unsigned long long)__double_as_longlong(Gt), __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -2584,6 +2586,118 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     if (tid == 0) {
         __hip_atomic_store(F.done + item, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_fetch_add(F.cnt + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---- two colour classes per launch ------------------------------------------------
+//
+// With two pending layers the launches alternate: N (finds one layer pending, applies
+// it in registers, writes nothing) and W (finds two, applies them, writes the residual
+// back).  A W launch depends on the N launch before it ONLY through that colour's G
+// rows (1 KiB per window): the residual it reads was last written one launch earlier.
+// k_mh_pair therefore runs an N colour and the W colour after it in ONE launch:
+//   * items = the windows of colour A (N) followed by those of colour B (W), one
+//     workgroup each, drawn as tickets so that a waiting workgroup's predecessors are
+//     always running or done;
+//   * an A item publishes its G row with agent-scope (sc1) stores and raises its flag;
+//   * a B item waits for the flags of the <= 4 A windows that intersect its own, loads
+//     their G rows with sc1 loads, and otherwise is a plain k_mh_ws W item: residual
+//     loads and stores are ordinary cached accesses.  No race on the residual: the one
+//     A window that covers a cell has read it before it raises the flag the covering
+//     B window waits for.
+// One kernel boundary, one all-at-once setup and one decision tail less per colour
+// pair; bit-identical to the per-colour launches (same windows, same arithmetic).
+struct MHPair {
+    const int4 *ent;   // [items] {y, x, real, colour ordinal} (the context's flow tables)
+    const int *lat;    // [K][LY*LX] lattice point -> index in the colour's list
+    unsigned *done;    // [items] epoch in which the item finished
+    unsigned *ctl;     // ticket counter (monotonic over launches)
+    unsigned *err;     // sticky: a wait timed out
+    int first_a, n_a;  // items of colour A: [first_a, first_a + n_a)
+    int first_b, n_b;  // items of colour B
+    int ka;            // ordinal of colour A among the active colours (lat table row)
+    int a_cy, a_cx;    // colour class of A
+    int LY, LX;
+    unsigned ticket_base;  // value of *ctl when this launch starts
+    unsigned epoch;
+    double *G_a, *G_b;     // G rows written by A items / B items
+};
+
+template <int NS, bool UV, int U, int K>
+__global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_t sweep) {
+    extern __shared__ double smem[];
+    constexpr int NT = NS + 64;
+    constexpr int M = 2;
+    const int tid = threadIdx.x;
+    const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
+    int *s_item = reinterpret_cast<int *>(smem + mh_ws_lds_doubles(NS, P.HL, P.Dp, P.N, P.npos, M));
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    if (tid == 0)
+        *s_item = (int)(__hip_atomic_fetch_add(F.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                        F.ticket_base);
+    __syncthreads();
+    const int t = __builtin_amdgcn_readfirstlane(*s_item);
+    if (t >= F.n_a + F.n_b) return;
+    const bool is_b = t >= F.n_a;
+    const int item = is_b ? F.first_b + (t - F.n_a) : F.first_a + t;
+    const int4 ent = F.ent[item];
+    MHWsItem I;
+    I.y = ent.x;
+    I.x = ent.y;
+    I.real = ent.z;
+    // pending layers: those of the launch arguments, and for a B item colour A on top
+    mh_ws_layers_from_args(P, I);
+    bool ok = true;
+    if (is_b) {
+        // (the host fuses a pair only when exactly ONE layer is pending: static index 1)
+        I.lay_cy[1] = F.a_cy;
+        I.lay_cx[1] = F.a_cx;
+        I.lay_G[1] = F.G_a;
+        I.n_lay = 2;
+        I.write_back = 1;
+        I.Gcur = F.G_b;
+        if (tid < 4) {
+            // the A windows that intersect this one inside the domain
+            const int wy = (tid >> 1) ? min(I.y + fhh, P.dy1 - 1) : max(I.y - fhh, P.dy0);
+            const int wx = (tid & 1) ? min(I.x + fhw, P.dx1 - 1) : max(I.x - fhw, P.dx0);
+            const int sy = covering_lattice(wy, F.a_cy, P.fh, fhh);
+            const int sx = covering_lattice(wx, F.a_cx, P.fw, fhw);
+            const int iy = (sy - F.a_cy) / P.fh + 1, ix = (sx - F.a_cx) / P.fw + 1;
+            int li = -1;
+            if (iy >= 0 && iy < F.LY && ix >= 0 && ix < F.LX)
+                li = F.lat[((long)F.ka * F.LY + iy) * F.LX + ix];
+            if (li >= 0) ok = flow_wait(F.done + F.first_a + li, F.epoch, false, F.err);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // keep the loads below the polls
+    } else {
+        I.write_back = 0;
+        I.Gcur = F.G_a;
+    }
+    if (__syncthreads_or(!ok)) return;  // a timed-out wait (*F.err is set: the host reports it)
+    const bool idle = !I.real && (I.n_lay == 0 || !I.write_back);
+    if (idle) {
+        if (!is_b) mh_ws_zero_row<true>(P, I); else mh_ws_zero_row<false>(P, I);
+    } else {
+        mh_ws_preds<M>(P, I);
+        MHGpRegs<M, K> gv;
+        if (is_b)
+            mh_ws_gp_load<M, K, true>(P, I, NT, gv);   // colour A's rows come from this launch
+        else
+            mh_ws_gp_load<M, K, false>(P, I, NT, gv);
+        mh_ws_table<M>(P, S, I, NT);
+        mh_ws_gp_store<M, K>(P, S, I, NT, gv);
+        __syncthreads();
+        if (is_b)
+            mh_ws_run<NS, UV, false, U, M, false>(P, S, I, sweep, item);
+        else
+            mh_ws_run<NS, UV, false, U, M, true>(P, S, I, sweep, item);
+    }
+    if (!is_b) {
+        // every storing wave drains its sc1 stores, then one lane raises the flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(F.done + item, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

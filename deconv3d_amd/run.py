@@ -64,7 +64,10 @@ class Run:
     ``write_every`` iterations) and ``resume_state`` (the ``<prefix>_state.npz``
     of a checkpoint: the sweep numbering, the accepted count and hence the
     random-number streams continue where the checkpointed run stopped; pass the
-    checkpoint's ``<prefix>_parameters.npy`` as ``initial_parameters``).
+    checkpoint's ``<prefix>_parameters.npy`` as ``initial_parameters``), and
+    ``chain_file`` (file prefix: chain and likelihoods live in memory-mapped
+    ``<prefix>_chain.npy`` / ``<prefix>_likelihoods.npy`` instead of RAM, written as the
+    device streams saved sweeps out -- a 300x300 chain of 50 000 sweeps is 108 GB).
     """
 
     def __init__(
@@ -87,6 +90,7 @@ class Run:
         sweeps_per_call=None,
         checkpoint=None,
         resume_state=None,
+        chain_file=None,
     ):
         # lib/run.py:112-114
         assert keep_one_in > 0, "keep_one_in= MUST be a positive integer"
@@ -198,10 +202,21 @@ class Run:
         self.seed = int(seed)
 
         # ---- chain storage (lib/run.py:267-281), NaN instead of garbage ------
+        self._chain_file = chain_file
         try:
-            self.chain = np.full(
-                (cnt_iterations, cube_height, cube_width, parameters_count), np.nan)
-            likelihoods = np.full((cnt_iterations, cube_height, cube_width), np.nan)
+            chain_shape = (cnt_iterations, cube_height, cube_width, parameters_count)
+            if chain_file is not None:
+                # pages are created as saved sweeps arrive; slots never written (early
+                # stop) are NaN-filled at the end like the in-memory chain
+                self.chain = np.lib.format.open_memmap(
+                    "%s_chain.npy" % chain_file, mode="w+", dtype=np.float64, shape=chain_shape)
+                likelihoods = np.lib.format.open_memmap(
+                    "%s_likelihoods.npy" % chain_file, mode="w+", dtype=np.float64,
+                    shape=chain_shape[:3])
+                likelihoods[0] = np.nan
+            else:
+                self.chain = np.full(chain_shape, np.nan)
+                likelihoods = np.full(chain_shape[:3], np.nan)
         except MemoryError:
             self.logger.error("Not enough RAM available for that many iterations. "
                               "Use a higher value in the keep_one_in= parameter.")
@@ -305,6 +320,12 @@ class Run:
                 self._write_checkpoint(checkpoint, cur_iteration, accepted_count)
         self.iterations_done = cur_iteration
         self.acceptance_rate = float(accepted_count) / float(max(spaxels_count * cur_iteration, 1))
+        if chain_file is not None:
+            n_valid = (cur_iteration - 1) // self.keep_one_in + 1
+            self.chain[n_valid:] = np.nan
+            likelihoods[n_valid:] = np.nan
+            self.chain.flush()
+            likelihoods.flush()
 
         # ---- outputs (lib/run.py:539-549) ------------------------------------
         self.likelihoods = likelihoods

@@ -212,18 +212,22 @@ def test_mh_chain_matches_oracle_update_by_update(name):
 @pytest.mark.parametrize("name", ["c1", "odd_depth", "big_fsf", "tiny"])
 def test_write_back_schemes_are_bit_identical(monkeypatch, name):
     """Deferred write-back (wave-specialised k_mh_ws with three, one or two pending
-    layers; k_mh_flow: one launch per sweep with per-window dependencies; plain
+    layers; k_mh_pair: two colour classes per launch with per-window G hand-off;
+    k_mh_flow: one launch per sweep with per-window dependencies; plain
     k_mh_defer: the next colour applies the pending update), immediate re-read and
     immediate register-resident kernels are the same arithmetic: bit-identical
     chains and residuals."""
     case = make_case(name)
     outs = []
     for env in ({"D3D_MH_DEFER": "1"}, {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "1"},
-                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2"}, {"D3D_MH_DEFER": "1", "D3D_MH_FLOW": "1"},
+                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2"},                       # k_mh_pair
+                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "0"},  # one colour per launch
+                {"D3D_MH_DEFER": "1", "D3D_MH_FLOW": "1"},
                 {"D3D_MH_DEFER": "2"},
                 {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "0"},
                 {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "8"}):   # same workgroup size: same summation order
-        for k in ("D3D_MH_DEFER", "D3D_MH_MAXIT", "D3D_MH_NT", "D3D_MH_FLOW", "D3D_MH_LAYERS"):
+        for k in ("D3D_MH_DEFER", "D3D_MH_MAXIT", "D3D_MH_NT", "D3D_MH_FLOW", "D3D_MH_LAYERS",
+                  "D3D_MH_PAIR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -319,3 +319,26 @@ def test_streamed_chain_equals_the_synchronous_one():
         np.testing.assert_array_equal(chain, want_chain)
         np.testing.assert_array_equal(dlog, want_dlog)
         assert acc == total
+
+
+def test_memory_mapped_chain(tmp_path):
+    """chain_file=: chain and likelihoods are written into memory-mapped .npy files as
+    the device streams them out; same numbers as the in-memory chain, early stop
+    leaves NaN slots, and the files reload with numpy."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=4)
+    kw = dict(variance=var, seed=3, keep_one_in=2, min_acceptance_rate=0.)
+    ram = d3d.Run(cube, inst, max_iterations=13, **kw)
+    name = str(tmp_path / "big")
+    disk = d3d.Run(cube, inst, max_iterations=13, chain_file=name, **kw)
+    assert isinstance(disk.chain, np.memmap)
+    np.testing.assert_array_equal(np.asarray(disk.chain), ram.chain)
+    np.testing.assert_array_equal(np.asarray(disk.likelihoods), ram.likelihoods)
+    back = np.load(name + "_chain.npy", mmap_mode="r")
+    np.testing.assert_array_equal(np.asarray(back), ram.chain)
+    np.testing.assert_array_equal(disk.parameters, ram.parameters)
+    stopped = d3d.Run(cube, inst, max_iterations=40, chain_file=str(tmp_path / "stop"),
+                      variance=var, seed=3, keep_one_in=2, min_acceptance_rate=0.999,
+                      jump_amplitude=5.0)
+    assert stopped.iterations_done < 40
+    n_valid = (stopped.iterations_done - 1) // 2 + 1
+    assert np.isnan(stopped.chain[n_valid:]).all() and not np.isnan(stopped.chain[:n_valid]).any()
