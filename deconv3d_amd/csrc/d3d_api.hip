@@ -179,7 +179,8 @@ struct d3d_ctx {
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
     // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
     // monotonic ticket counter, so that nothing needs clearing between launches
-    int mh_pair = 1;               // D3D_MH_PAIR=0: one launch per colour class
+    int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
+                                   // measured 43.0 vs 42.0 us per colour: opt-in)
     unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item
     unsigned pair_epoch = 0, pair_tickets = 0;
     std::vector<int> flow_first;   // first item of every active colour (+ total)
@@ -925,8 +926,7 @@ int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
 template <bool UV, int U, int K>
 int launch_mh_pair_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHPair &F, uint32_t sweep) {
     constexpr int NS = 256;
-    size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, 2) * sizeof(double);
-    lds += 16;  // the ticket
+    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, 2) * sizeof(double);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_pair<NS, UV, U, K>), dim3((unsigned)(F.n_a + F.n_b)),
                        dim3(NS + 64), lds, c->stream, P, F, sweep);
     HIP_TRY(hipGetLastError());
@@ -953,6 +953,7 @@ int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
     F.LX = c->flow_LX;
     F.ticket_base = c->pair_tickets;
     F.epoch = ++c->pair_epoch;
+    F.diag = getenv("D3D_PAIR_DIAG") ? atoi(getenv("D3D_PAIR_DIAG")) : 0;
     const int ga = pend_free_buf(c);
     int gb = 0;
     for (int b = 0; b < 4; ++b) {
@@ -2115,7 +2116,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     unsigned long long acc = 0;
     unsigned flow_err = 0;
     HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
-    if (flow || c->mh_pair)
+    if (flow || c->mh_pair)  // (both kernels raise *flow_err when a flag wait times out)
         HIP_TRY(hipMemcpyAsync(&flow_err, c->flow_err, sizeof flow_err, hipMemcpyDeviceToHost,
                                c->stream));
     while (snaps.count > 0)

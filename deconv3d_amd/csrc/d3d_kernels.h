@@ -2597,16 +2597,22 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
 // rows (1 KiB per window): the residual it reads was last written one launch earlier.
 // k_mh_pair therefore runs an N colour and the W colour after it in ONE launch:
 //   * items = the windows of colour A (N) followed by those of colour B (W), one
-//     workgroup each, drawn as tickets so that a waiting workgroup's predecessors are
-//     always running or done;
+//     workgroup each, in blockIdx order;
 //   * an A item publishes its G row with agent-scope (sc1) stores and raises its flag;
 //   * a B item waits for the flags of the <= 4 A windows that intersect its own, loads
 //     their G rows with sc1 loads, and otherwise is a plain k_mh_ws W item: residual
 //     loads and stores are ordinary cached accesses.  No race on the residual: the one
 //     A window that covers a cell has read it before it raises the flag the covering
 //     B window waits for.
-// One kernel boundary, one all-at-once setup and one decision tail less per colour
-// pair; bit-identical to the per-colour launches (same windows, same arithmetic).
+// One kernel boundary less per colour pair; bit-identical to the per-colour launches
+// (same windows, same arithmetic; tests/test_gpu_parity.py, test_gpu_full_size.py).
+// OPT-IN (D3D_MH_PAIR=1).  Measured on MI355X at 300x300x128 / 11x11: 43.0 us per colour
+// against 42.0 for one launch per colour.  The boundary it saves (an empty pair launch
+// costs 3.7 us) is paid back as dependency wait: all windows of colour A are resident at
+// once, share the HBM stream equally and therefore finish TOGETHER, so no B window can
+// start early -- with the waits switched off (wrong results, timing only) the same launch
+// takes 38.8 us per colour.  A first version drew tickets from one atomic counter: 1568
+// same-address atomics serialise at ~13 ns each, an empty launch took 20 us.
 struct MHPair {
     const int4 *ent;   // [items] {y, x, real, colour ordinal} (the context's flow tables)
     const int *lat;    // [K][LY*LX] lattice point -> index in the colour's list
@@ -2620,6 +2626,8 @@ struct MHPair {
     int LY, LX;
     unsigned ticket_base;  // value of *ctl when this launch starts
     unsigned epoch;
+    int diag;              // D3D_PAIR_DIAG (timing experiments only; results are then WRONG):
+                           // 1 B items do not wait, 2 B items do nothing, 4 A items do nothing
     double *G_a, *G_b;     // G rows written by A items / B items
 };
 
@@ -2630,16 +2638,25 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     constexpr int M = 2;
     const int tid = threadIdx.x;
     const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
-    int *s_item = reinterpret_cast<int *>(smem + mh_ws_lds_doubles(NS, P.HL, P.Dp, P.N, P.npos, M));
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
-    if (tid == 0)
-        *s_item = (int)(__hip_atomic_fetch_add(F.ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                        F.ticket_base);
-    __syncthreads();
-    const int t = __builtin_amdgcn_readfirstlane(*s_item);
+    // Items in blockIdx order, NOT tickets from an atomic counter: 1568 same-address
+    // atomics per launch serialise at ~13 ns each -- an empty launch took 20 us.  The
+    // dispatcher hands out the workgroups of a 1-D grid in index order per XCD, and every
+    // A item precedes every B item, so an A item is never kept out of a slot by a B item
+    // that waits for it; should that ever fail, flow_wait's time-out raises *F.err and
+    // the host reports it instead of hanging.
+    const int t = (int)blockIdx.x;
     if (t >= F.n_a + F.n_b) return;
     const bool is_b = t >= F.n_a;
     const int item = is_b ? F.first_b + (t - F.n_a) : F.first_a + t;
+    if (F.diag) {
+        if (is_b && (F.diag & 2)) return;
+        if (!is_b && (F.diag & 4)) {
+            if (tid == 0)
+                __hip_atomic_store(F.done + item, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     const int4 ent = F.ent[item];
     MHWsItem I;
     I.y = ent.x;
@@ -2656,7 +2673,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
         I.n_lay = 2;
         I.write_back = 1;
         I.Gcur = F.G_b;
-        if (tid < 4) {
+        if (tid < 4 && !(F.diag & 1)) {
             // the A windows that intersect this one inside the domain
             const int wy = (tid >> 1) ? min(I.y + fhh, P.dy1 - 1) : max(I.y - fhh, P.dy0);
             const int wx = (tid & 1) ? min(I.x + fhw, P.dx1 - 1) : max(I.x - fhw, P.dx0);

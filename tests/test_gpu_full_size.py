@@ -107,10 +107,10 @@ def test_sweep_dataflow_kernel_equals_per_colour_launches(monkeypatch, problem, 
     var = problem["var"] if uniform else problem["var"] * (
         0.75 + 0.5 * np.random.default_rng(5).random(problem["var"].shape))
     outs = []
-    # (the default -- two layers -- runs two colour classes per launch, k_mh_pair;
-    # D3D_MH_PAIR=0 is one launch per colour class)
+    # (D3D_MH_PAIR=1: two colour classes per launch, k_mh_pair, G rows handed over inside
+    # the launch)
     for env in ({"D3D_MH_FLOW": "1"}, {"D3D_MH_LAYERS": "1"}, {"D3D_MH_LAYERS": "2"},
-                {"D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "0"}, {"D3D_MH_LAYERS": "3"}):
+                {"D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "1"}, {"D3D_MH_LAYERS": "3"}):
         for k in ("D3D_MH_FLOW", "D3D_MH_DEFER", "D3D_MH_LAYERS", "D3D_MH_PAIR"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():

@@ -220,8 +220,8 @@ def test_write_back_schemes_are_bit_identical(monkeypatch, name):
     case = make_case(name)
     outs = []
     for env in ({"D3D_MH_DEFER": "1"}, {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "1"},
-                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2"},                       # k_mh_pair
-                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "0"},  # one colour per launch
+                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2"},
+                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "1"},  # k_mh_pair
                 {"D3D_MH_DEFER": "1", "D3D_MH_FLOW": "1"},
                 {"D3D_MH_DEFER": "2"},
                 {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "0"},
