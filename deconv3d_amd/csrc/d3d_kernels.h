@@ -2194,14 +2194,18 @@ __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I
     const int Dp = P.Dp;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
+        // (values first, select second: a select between the two array ELEMENTS is turned
+        // into a load from a selected address, which keeps the item struct in scratch --
+        // three dependent scratch round trips in every workgroup's setup)
+        const int py0 = I.psy0[j], py1 = I.psy1[j], px0 = I.psx0[j], px1 = I.psx1[j];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int i = threadIdx.x + k * NT;
             R.v[j][k] = 0.0;
             if (j < I.n_lay && i < 4 * Dp) {
                 const int q = i / Dp, z = i - q * Dp;
-                const int sy = (q >> 1) ? I.psy1[j] : I.psy0[j];
-                const int sx = (q & 1) ? I.psx1[j] : I.psx0[j];
+                const int sy = (q >> 1) ? py1 : py0;
+                const int sx = (q & 1) ? px1 : px0;
                 if (sy >= 0 && sx >= 0) {
                     const double *src =
                         I.lay_G[j] + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
