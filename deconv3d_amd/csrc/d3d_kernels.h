@@ -2194,9 +2194,6 @@ __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I
     const int Dp = P.Dp;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        // (values first, select second: a select between the two array ELEMENTS is turned
-        // into a load from a selected address, which keeps the item struct in scratch --
-        // three dependent scratch round trips in every workgroup's setup)
         const int py0 = I.psy0[j], py1 = I.psy1[j], px0 = I.psx0[j], px1 = I.psx1[j];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
