@@ -455,7 +455,7 @@ def main():
         eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
     slots_ms = eng.timer_stop() / max(args.conv_iters, 1)
     roofline_conv = conv_entry(slots_ms, "k_conv_rows (LSF x FSF in one pass, slot layout)",
-                               "k_conv_rows")
+                               "k_conv_rows<11, 15, true, true, false, 1>")
     roofline_conv["algorithmic_bytes"] = conv_bytes
     roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
                                           "k_spatial_z")
@@ -546,8 +546,8 @@ def main():
                 eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
             g_ms = eng.timer_stop() / max(args.conv_iters, 1)
             out["roofline_conv_gaussian"] = conv_entry(
-                g_ms, "k_spatial_sep_lsf (Gaussian 11x11 FSF = outer product; LSF in the same pass)",
-                "k_spatial_sep_lsf")
+                g_ms, "k_conv_rows, outer-product form (Gaussian 11x11 FSF; LSF in the same pass)",
+                "k_conv_rows<11, 15, true, true, false, 2>")
             out["roofline_conv_gaussian"]["fp64_tflops"] = round(
                 2.0 * (fh + fw + ntaps_lsf) * D * H * W / (g_ms * 1e-3) / 1e12, 2)
             out["roofline_conv_gaussian"].pop("fp64_frac", None)

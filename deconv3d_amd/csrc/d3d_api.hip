@@ -846,8 +846,29 @@ template <bool UV, int U, int M, int K>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K>), dim3(grid), dim3(NS + 64),
-                       lds, c->stream, P, sweep);
+    // (the number of pending layers as a template constant: see k_mh_ws)
+    switch (P.n_lay <= M ? P.n_lay : -1) {
+        case 0:
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0>), dim3(grid),
+                               dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 1:
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1>), dim3(grid),
+                               dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 2:
+            if constexpr (M >= 2)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2>), dim3(grid),
+                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 3:
+            if constexpr (M >= 3)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3>), dim3(grid),
+                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        default:
+            return fail(D3D_ERR_STATE, "internal: %d pending layers for a %d-layer kernel", P.n_lay, M);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -2401,7 +2401,11 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 }
 
 // K: registers per thread and layer that stage the pending G rows (4*Dp <= K*(NS+64))
-template <int NS, bool UV, int U, int M, int K>
+// NL: the number of pending layers of this launch (== P.n_lay; -1: read it at run time).
+// As a compile-time constant the "layer j is live" tests of the setup fold away -- and with
+// them a store at a run-time index that kept the item's small arrays, and three dependent
+// scratch round trips, in every workgroup's setup.
+template <int NS, bool UV, int U, int M, int K, int NL = -1>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
@@ -2413,6 +2417,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     I.x = ent.y;
     I.real = ent.z;
     mh_ws_layers_from_args(P, I);
+    if constexpr (NL >= 0) I.n_lay = NL;
     // a virtual position only matters to a launch that writes the residual back
     if (!I.real && (I.n_lay == 0 || !I.write_back)) {
         mh_ws_zero_row<false>(P, I);

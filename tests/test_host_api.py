@@ -251,3 +251,30 @@ def test_bench_refuses_multi_gpu_without_devices():
                        text=True, timeout=300)
     assert r.returncode != 0
     assert "HIP device" in r.stderr and not r.stdout.strip()
+
+
+def test_fits_header_cards_survive_awkward_values(tmp_path):
+    """Strings with quotes or longer than a card, and non-finite numbers, in a header
+    written by Cube.to_fits (lib/run.py:797-806 writes the run's cubes with the input
+    cube's metadata)."""
+    from deconv3d_amd.cube import read_fits, write_fits
+    data = np.arange(24, dtype=np.float64).reshape(2, 3, 4)
+    header = {"OBJECT": "O'Neill's galaxy", "COMMENT1": "x" * 100, "NANVAL": float("nan"),
+              "INFVAL": float("inf"), "EXPTIME": 12.5, "NSCANS": 3, "FLAG": True,
+              "TRAIL": "ends with quote'"}
+    path = str(tmp_path / "c.fits")
+    write_fits(path, data, header, clobber=True)
+    raw = open(path, "rb").read()
+    assert len(raw) % 2880 == 0
+    back, h = read_fits(path)
+    np.testing.assert_array_equal(back, data)
+    assert h["OBJECT"] == "O'Neill's galaxy" and h["TRAIL"] == "ends with quote'"
+    assert h["COMMENT1"] == "x" * 68
+    assert "NANVAL" not in h and "INFVAL" not in h
+    assert h["EXPTIME"] == 12.5 and h["NSCANS"] == 3 and h["FLAG"] is True
+    # every card is exactly 80 characters and every string card has its closing quote
+    head = raw[:raw.index(b"END" + b" " * 77) + 80].decode("latin1")
+    for i in range(0, len(head), 80):
+        card = head[i:i + 80]
+        if card[8:10] == "= " and card[10:].lstrip().startswith("'"):
+            assert card.rstrip().endswith("'"), card
