@@ -236,3 +236,91 @@ def test_update_records_replay_on_another_context():
     finally:
         a.close()
         b.close()
+
+
+def test_mh_sweeps_runs_phases_and_rccl_exchanges_from_one_call():
+    """d3d_mh_sweeps on a context with a communicator: phases, RCCL halo exchanges between
+    them and the parameter gather + from-scratch residual, all queued from ONE host call.
+    One GPU allows one rank, so the plans send every rectangle to the rank itself (onto
+    the same cells): the chain must equal the partitioned context without a communicator."""
+    case = make_case("tile_b")
+    fh, fw = case["fsf"].shape
+    lay = tiling.TileLayout(case["H"], case["W"], fh, fw, 2, 1)
+    ref_params, ref_err, accepted, _ = single_context(case, lay, 35.0, 9, 4, refresh_every=2)
+    D, H, W = case["D"], case["H"], case["W"]
+    with _lib.Engine((D, H, W), (fh, fw)) as eng:
+        eng.set_taps(case["fsf"], case["lsf"])
+        eng.set_data(case["data"], case["var"], mask=case["mask"])
+        tiling.apply_parts(eng, lay)
+        for ph in lay.phases:
+            t = lay.touched(0, ph) or lay.touched(1, ph)
+            eng.halo_plan(ph, [[0, 0, *t, *t]])
+        eng.halo_plan(_lib.PLAN_PARAMS, [[0, 1, 3, 9, 0, W, 3, 9, 0, W]])
+        eng.set_params(case["init"])
+        eng.mh_config(case["min_b"], case["max_b"], 0.1, 35.0, seed=9, refresh_every=2)
+        eng.residual(fetch=False)
+        with pytest.raises(RuntimeError):        # plans but no communicator yet
+            eng.mh_sweeps(1, 1)
+        eng.comm_init(1, 0, _lib.comm_unique_id())
+        got = eng.mh_sweeps(4, 1)
+        np.testing.assert_array_equal(eng.get_params(), ref_params)
+        np.testing.assert_array_equal(eng.download_slot(_lib.SLOT_ERR), ref_err)
+        assert got == accepted
+        eng.comm_destroy()
+
+
+GLOO_WORKER = r"""
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+from deconv3d_amd import tiling
+from tests.cases import make_case
+
+dist.init_process_group(backend="gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+case = make_case("tile_a")
+fh, fw = case["fsf"].shape
+lay = tiling.TileLayout(case["H"], case["W"], fh, fw, *tiling.tile_grid_for(world))
+err0 = np.load(os.path.join(%(out)r, "err0.npy"))
+eng = tiling.make_tile_engine(lay, rank, case["data"], case["var"], case["mask"], case["fsf"],
+                              case["lsf"], case["init"], case["min_b"], case["max_b"], 0.1, 35.0, 77,
+                              device=0, err=err0)
+tables = tiling.plan_tables(lay, rank)
+for s in (1, 2, 3):
+    tiling.sweep_distributed(eng, lay, tables, s, dist, torch)
+(y0, y1, x0, x1), p = tiling.gather_params(lay, rank, eng)
+np.save(os.path.join(%(out)r, "params_%%d.npy" %% rank), p)
+np.save(os.path.join(%(out)r, "rect_%%d.npy" %% rank), np.array([y0, y1, x0, x1]))
+eng.close()
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_gloo_ranks_on_one_gpu_are_bit_identical(tmp_path):
+    """The multi-process form of the tiled chain with device engines: two ranks (both on
+    this GPU), halos staged through the host over gloo, against the partitioned single
+    context."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    case = make_case("tile_a")
+    lay = tiling.TileLayout(case["H"], case["W"], *case["fsf"].shape, *tiling.tile_grid_for(2))
+    ref_params, _, _, err0 = single_context(case, lay, 35.0, 77, 3)
+    np.save(tmp_path / "err0.npy", err0)
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER % {"root": root, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)]
+    res = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    live = case["mask"] == 1
+    for r in range(2):
+        y0, y1, x0, x1 = np.load(tmp_path / ("rect_%d.npy" % r))
+        m = live[y0:y1, x0:x1]
+        np.testing.assert_array_equal(np.load(tmp_path / ("params_%d.npy" % r))[m],
+                                      ref_params[y0:y1, x0:x1][m])
