@@ -179,7 +179,6 @@ struct d3d_ctx {
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
     // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
     // monotonic ticket counter, so that nothing needs clearing between launches
-    int mh_wide = 1;               // D3D_MH_WIDE=0: never use the 960-thread form for small launches
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)
     unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item
@@ -843,8 +842,9 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV, int U, int M, int K, int NS = 256>
+template <bool UV, int U, int M, int K>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
     // (the number of pending layers as a template constant: see k_mh_ws)
     switch (P.n_lay <= M ? P.n_lay : -1) {
@@ -884,9 +884,12 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
     // (with several layers most launches only read: two positions in flight pay at
-    // full size, 43.3 -> 42.6 us per colour; EIGHT positions for launches that do not fill
-    // the chip measured slower than four: a 150x300 tile part 6.41 vs 5.26 ms per sweep,
-    // 32x16x16 10.45 vs 9.95 us per launch -- 165-175 VGPRs, two wavefronts per SIMD)
+    // full size, 43.3 -> 42.6 us per colour.  Round 2, for launches that do not fill the
+    // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
+    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); FIFTEEN
+    // streaming wavefronts per window instead of four (k_mh_ws<960>) helped 128-channel
+    // tile parts, 4.13 -> 3.41 ms per sweep for an 8x1 rank, but cost shallow cubes,
+    // 9.9 -> 12.2 us per launch at 32x16x16, and another grouping of the window sums)
     if (c->mh_layers >= 3) {  // Dp <= 160
         if (small) return launch_mh_ws_um<UV, 4, 3, 2>(c, P, grid, sweep);
         return launch_mh_ws_um<UV, 2, 3, 2>(c, P, grid, sweep);
@@ -899,14 +902,6 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
         if (small) return launch_mh_ws_um<UV, 4, 2, 2>(c, P, grid, sweep);
         return launch_mh_ws_um<UV, 2, 2, 2>(c, P, grid, sweep);
     }
-    // A launch of at most one workgroup per CU is bound by how fast ONE workgroup gets
-    // through its window (121 positions through four wavefronts, ~2 us per round trip):
-    // fifteen streaming wavefronts instead of four (k_mh_ws<960>; D3D_MH_WIDE=0: off).
-    // Another grouping of the window sums than the 256-thread form: chains agree to
-    // rounding, not bit for bit -- a given launch size always takes the same form, so a
-    // tiled chain and the single context given the same parts still agree bit for bit.
-    if (small && c->mh_wide && grid <= (unsigned)c->flow_grid / 4 && c->Dp <= 256 && 960 % c->HL == 0)
-        return launch_mh_ws_um<UV, 2, 1, 1, 960>(c, P, grid, sweep);
     if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
 }
@@ -1080,7 +1075,6 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
     if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
-    if (const char *e = getenv("D3D_MH_WIDE")) c->mh_wide = atoi(e);
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
     // other MH kernels keep one layer
