@@ -34,11 +34,14 @@ device-to-device copies between contexts of one process (`sweep_loopback`, the
 one-GPU rehearsal and the bit-identity tests); host-staged torch.distributed
 (gloo) for multi-process rehearsal on a box with fewer GPUs than ranks.
 
-What this buys: the colour classes of a part are a dependent chain of fh*fw
-launches, and a launch costs ~10 us however few windows it holds, so a sweep
-cannot take less than (phases) x fh*fw x 10 us.  Row strips (N x 1: two phases)
-are therefore the fast layout; 2-D grids (four phases) are supported and exact
-but slower at 300x300.  The throughput mode across GPUs is the ensemble.
+What this buys -- measured, DESIGN.md section 7: the colour classes of a part are a
+dependent chain of fh*fw launches, and a launch that does not fill the chip costs
+~17 us at 128 channels however few windows it holds.  One interior rank of an 8 x 1
+tiling of 300x300x128 computes 4.1 ms per sweep alone against 5.1 ms for the whole
+cube on one GPU: the tiled chain is the mode for a cube or a chain that must be SPLIT
+(or one much larger than 300x300); it does not make a 300x300 chain faster.  Row
+strips (N x 1: two phases) are the default layout; 2-D grids (four phases) are
+supported and exact.  The throughput mode across GPUs is the ensemble.
 
 Engines are duck-typed (`mh_phase`, `halo_pack/unpack`, `halo_download/upload`,
 ...): the product engine is `_lib.Engine`; the CPU tests drive the same code with
