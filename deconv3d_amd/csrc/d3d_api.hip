@@ -979,7 +979,6 @@ int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
     F.LX = c->flow_LX;
     F.ticket_base = c->pair_tickets;
     F.epoch = ++c->pair_epoch;
-    F.diag = getenv("D3D_PAIR_DIAG") ? atoi(getenv("D3D_PAIR_DIAG")) : 0;
     const int ga = pend_free_buf(c);
     int gb = 0;
     for (int b = 0; b < 4; ++b) {

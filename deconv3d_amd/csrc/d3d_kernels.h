@@ -2632,8 +2632,6 @@ struct MHPair {
     int LY, LX;
     unsigned ticket_base;  // value of *ctl when this launch starts
     unsigned epoch;
-    int diag;              // D3D_PAIR_DIAG (timing experiments only; results are then WRONG):
-                           // 1 B items do not wait, 2 B items do nothing, 4 A items do nothing
     double *G_a, *G_b;     // G rows written by A items / B items
 };
 
@@ -2655,14 +2653,6 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     if (t >= F.n_a + F.n_b) return;
     const bool is_b = t >= F.n_a;
     const int item = is_b ? F.first_b + (t - F.n_a) : F.first_a + t;
-    if (F.diag) {
-        if (is_b && (F.diag & 2)) return;
-        if (!is_b && (F.diag & 4)) {
-            if (tid == 0)
-                __hip_atomic_store(F.done + item, F.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
-        }
-    }
     const int4 ent = F.ent[item];
     MHWsItem I;
     I.y = ent.x;
@@ -2679,7 +2669,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
         I.n_lay = 2;
         I.write_back = 1;
         I.Gcur = F.G_b;
-        if (tid < 4 && !(F.diag & 1)) {
+        if (tid < 4) {
             // the A windows that intersect this one inside the domain
             const int wy = (tid >> 1) ? min(I.y + fhh, P.dy1 - 1) : max(I.y - fhh, P.dy0);
             const int wx = (tid & 1) ? min(I.x + fhw, P.dx1 - 1) : max(I.x - fhw, P.dx0);
