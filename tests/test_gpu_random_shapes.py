@@ -16,10 +16,12 @@ from oracle import deconv3d_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def draw_case(seed):
+def draw_case(seed, depth=None, extent=34):
     rng = np.random.default_rng(1000 + seed)
     D = int(rng.choice([1, 2, 3, 7, 16, 17, 31, 32, 33, 64, 65, 100, 128, 130]))
-    H, W = int(rng.integers(1, 34)), int(rng.integers(1, 34))
+    if depth is not None:
+        D = depth
+    H, W = int(rng.integers(1, extent)), int(rng.integers(1, extent))
     kind = rng.choice(["gauss", "ellipse", "rotated", "moffat", "random", "rect", "delta"])
     if kind == "gauss":
         fsf = O.gaussian_fsf_image(float(rng.uniform(0.8, 4.2)))
@@ -70,9 +72,23 @@ def draw_case(seed):
                 what="%s fsf %s, %s lsf, %s variance" % (kind, fsf.shape, lkind, vkind))
 
 
+def test_random_shape_at_depth_128_matches_oracle(seed128):
+    """The 128-channel kernels (k_conv_rows: one wavefront per spectrum, 15 columns per
+    workgroup) on drawn footprints up to 49x49, i.e. up to four column groups."""
+    check_case(draw_case(200 + seed128, depth=128 if seed128 % 4 else 127, extent=50), seed128)
+
+
+@pytest.fixture(params=range(10))
+def seed128(request):
+    return request.param
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("D3D_TEST_RANDOM_SHAPES", "32"))))
 def test_random_shape_matches_oracle(seed):
-    c = draw_case(seed)
+    check_case(draw_case(seed), seed)
+
+
+def check_case(c, seed):
     D, H, W = shape = (c["D"], c["H"], c["W"])
     # the oracle (like lib/run.py:153-162) drops spaxels with a NaN in their spectrum
     nan_spax = np.isnan(c["data"]).any(axis=0)
@@ -93,6 +109,10 @@ def test_random_shape_matches_oracle(seed):
         cube = np.random.default_rng(seed).normal(size=shape)
         out = eng.convolve(cube)
         refc = O.convolve_cube(cube, c["fsf"], c["lsf"])
+        assert np.max(np.abs(out - refc)) <= 1e-12 * np.max(np.abs(refc)), c["what"]
+        eng.upload_slot(_lib.SLOT_TMP0, cube)             # and between two device slots
+        eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+        out = eng.download_slot(_lib.SLOT_SIM)
         assert np.max(np.abs(out - refc)) <= 1e-12 * np.max(np.abs(refc)), c["what"]
         if mask.sum() == 0:
             return
