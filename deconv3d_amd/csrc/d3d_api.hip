@@ -619,12 +619,10 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
     A.xcd_remap = 1;
     auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM>;
     constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW>();
-    static bool attr_set = false;  // (per instantiation)
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    // > 64 KB of dynamic LDS has to be allowed per function AND per device: set on every
+    // launch (a host-side call of a few microseconds; this kernel is not in the MH loop)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
                        in, out, (const double *)(TSYM == 2 ? c->fsf_quad_sep : c->fsf_quad),
                        (const double *)c->lsf_dense, data);
