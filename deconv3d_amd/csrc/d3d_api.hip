@@ -722,9 +722,17 @@ void pend_push(d3d_ctx *c, int cy, int cx, int g) {
 // params -> SLOT_TMP0 (LSF lines) -> dst (sim, or residual when resid)
 int forward_into(d3d_ctx *c, double *dst, bool resid) {
     if (resid) pend_clear(c);  // a fresh residual supersedes pending updates
+    const double *data = resid ? c->slot[D3D_SLOT_DATA] : nullptr;
+    // FSF and LSF commute: where the spatial kernel can apply the LSF in its epilogue the
+    // lines are built raw (exp only) and the LSF costs no pass of its own
+    if (c->ntaps > 0 && can_fuse_lsf(c)) {
+        int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 0);
+        if (rc) return rc;
+        return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, data, true);
+    }
     int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 1);
     if (rc) return rc;
-    return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, resid ? c->slot[D3D_SLOT_DATA] : nullptr);
+    return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, data);
 }
 
 void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
@@ -1834,10 +1842,11 @@ int d3d_simulate(d3d_ctx *c, const double *params, int convolved, double *out) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->params_alt, params, (size_t)c->HW * 3 * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
-    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], convolved ? 1 : 0, c->params_alt);
+    const bool fuse = convolved && c->ntaps > 0 && can_fuse_lsf(c);  // as forward_into
+    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], (convolved && !fuse) ? 1 : 0, c->params_alt);
     if (rc) return rc;
     if (!convolved) return download_cube(c, c->slot[D3D_SLOT_TMP0], out);
-    rc = launch_spatial(c, c->slot[D3D_SLOT_TMP0], c->slot[D3D_SLOT_SIM], nullptr);
+    rc = launch_spatial(c, c->slot[D3D_SLOT_TMP0], c->slot[D3D_SLOT_SIM], nullptr, fuse);
     if (rc) return rc;
     return download_cube(c, c->slot[D3D_SLOT_SIM], out);
 }

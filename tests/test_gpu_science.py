@@ -113,7 +113,7 @@ def test_reference_mat_fixture_chain_recovers_the_theoretical_parameters():
     mean, std = tail.mean(0), tail.std(0)
     np.testing.assert_allclose(run.parameters[live], mean[live], rtol=1e-12, atol=1e-12)
     bright = live & (truth[..., 0] > np.percentile(truth[..., 0][live], 50))
-    z = ((mean - truth) / std)[bright]
+    z = (mean - truth)[bright] / std[bright]
     assert np.all(np.sqrt(np.mean(z ** 2, axis=0)) < 1.6), np.sqrt(np.mean(z ** 2, axis=0))
     assert np.mean(np.abs(z) < 3) > 0.98
     dev = np.abs(mean - truth)[bright]
