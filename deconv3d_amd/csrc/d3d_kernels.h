@@ -2255,9 +2255,48 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
 // (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
 // COHG: only the G row this item leaves is published coherently (k_mh_pair: the other
 // colour class of the same launch reads it; the residual is handed over by nobody).
-template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH>
+template <int U>
+struct MHPre {
+    int vox[U];
+    double2 e[U], v[U];
+};
+
+// The loads of the first window round of a streaming thread (positions g + u G), issued
+// before the workgroup's setup: S.pos is not built yet, so the voxel index is computed
+// here -- the same expression as mh_ws_table's.
+template <int NS, bool UV, int U>
+__device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &I, MHPre<U> &R) {
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp;
+    const int G = NS / HL;
+    const int g = tid / HL, zl = tid - g * HL;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        R.vox[u] = -1;
+        R.e[u] = make_double2(0.0, 0.0);
+        R.v[u] = R.e[u];
+    }
+    if (tid >= NS || g >= G) return;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int p = g + u * G;
+        if (p < P.npos) {
+            const int dy = p / P.fw, dx = p - dy * P.fw;
+            const int yy = I.y + dy - fhh, xx = I.x + dx - fhw;
+            const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
+            R.vox[u] = inside ? yy * P.W + xx : -1;
+        }
+        const long idx = (long)max(R.vox[u], 0) * Dp + 2 * zl;
+        R.e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
+        if (!UV) R.v[u] = *reinterpret_cast<const double2 *>(P.ivar + idx);
+    }
+}
+
+template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
-                                          uint32_t sweep, long stamp_at) {
+                                          uint32_t sweep, long stamp_at,
+                                          const MHPre<U> *pre = nullptr) {
     constexpr int ROW = 1 + M;
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp, N = P.N;
@@ -2294,10 +2333,10 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             // workgroups are latency-bound (64^3: 14.6 -> 12.8 us per colour).
             // Positions outside the cube load voxel 0 and are skipped; the sums
             // still run in increasing p: bit-identical either way.
-#pragma unroll 4
-            for (int p0 = g; p0 < P.npos; p0 += U * G) {
-                int vox[U];
-                double2 e[U], v[U];
+            // PRE: the first round's loads were issued by the kernel before the setup
+            // (mh_ws_prefetch), so that the memory system is not idle while every
+            // workgroup of the launch computes its table; same values, same order.
+            auto issue = [&](int p0, int (&vox)[U], double2 (&e)[U], double2 (&v)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int p = p0 + u * G;
@@ -2312,6 +2351,8 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                     v[u] = vu;
                     if (!UV) v[u] = *reinterpret_cast<const double2 *>(P.ivar + idx);
                 }
+            };
+            auto consume = [&](int p0, int (&vox)[U], double2 (&e)[U], double2 (&v)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (vox[u] < 0) continue;
@@ -2343,6 +2384,26 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                     const double f = S.fsf[p];
                     D3D_ACCUM(e[u], v[u], f);
                 }
+            };
+            int p0 = g;
+            if constexpr (PRE) {
+                int vox[U];
+                double2 e[U], v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    vox[u] = pre->vox[u];
+                    e[u] = pre->e[u];
+                    v[u] = UV ? vu : pre->v[u];
+                }
+                consume(p0, vox, e, v);
+                p0 += U * G;
+            }
+#pragma unroll 4
+            for (; p0 < P.npos; p0 += U * G) {
+                int vox[U];
+                double2 e[U], v[U];
+                issue(p0, vox, e, v);
+                consume(p0, vox, e, v);
             }
             if (real) {
                 double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
@@ -2423,6 +2484,8 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         mh_ws_zero_row<false>(P, I);
         return;
     }
+    MHPre<U> pre;
+    mh_ws_prefetch<NS, UV, U>(P, I, pre);  // the window's first loads fly during the setup
     mh_ws_preds<M>(P, I);
     MHGpRegs<M, K> gv;
     mh_ws_gp_load<M, K, false>(P, I, NT, gv);  // in flight while the table is computed
@@ -2430,7 +2493,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
-    mh_ws_run<NS, UV, false, U, M>(P, S, I, sweep, blockIdx.x);
+    mh_ws_run<NS, UV, false, U, M, false, true>(P, S, I, sweep, blockIdx.x, &pre);
 }
 
 // ---- one launch per sweep: dataflow over the colour classes ----------------
