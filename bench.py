@@ -27,6 +27,11 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   cpu_baseline         -- the oracle's memory-sane numpy update loop on the host cores
   cpu_baseline_conv    -- the oracle's LSF (x) FSF convolution of one cube on the host
   host                 -- CPU model string and core counts of the box
+(the CPU baselines and the extra legs at N = 1 only), and at N > 1
+  config4_tiled        -- ONE chain of the same cube tiled over the same N GPUs (row strips,
+                          halo rectangles by RCCL inside the library), strong scaling:
+                          measured by child processes after the ensemble measurement, so a
+                          failure there costs an "error" note, never the contract line
 """
 from __future__ import annotations
 
@@ -218,6 +223,58 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+TILED_LEG_PORT_OFFSET = 173
+TILED_LEG_TIMEOUT_S = 240
+
+
+def start_tiled_leg(args, rank):
+    """The config-4 leg of a multi-GPU run: ONE chain tiled over the same N GPUs (halo
+    rectangles by RCCL inside the library), measured beside the ensemble `value`.  It
+    runs in child processes so that nothing it does can cost the contract line: every
+    rank starts its child HERE, before this process touches the GPU; the child imports
+    and then waits on its stdin until the ensemble measurement is over."""
+    import subprocess
+    import tempfile
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + TILED_LEG_PORT_OFFSET)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--mode", "tiled",
+           "--steps", str(min(args.steps, 50)), "--warmup", str(min(max(args.warmup, 1), 3)),
+           "--workload", args.workload, "--backend", args.backend, "--wait-stdin"]
+    if args.tiles:
+        cmd += ["--tiles", args.tiles]
+    errf = tempfile.TemporaryFile()
+    proc = subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE,
+                            stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                            stderr=errf)
+    return proc, errf
+
+
+def finish_tiled_leg(leg, rank):
+    """Release the child, wait for it (bounded), return rank 0's record or an error note."""
+    import subprocess
+    proc, errf = leg
+    try:
+        stdout, _ = proc.communicate(b"go\n", timeout=TILED_LEG_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.communicate()
+        return {"error": "tiled leg timed out after %d s" % TILED_LEG_TIMEOUT_S}
+    if rank != 0:
+        return None
+    for line in reversed((stdout or b"").decode(errors="replace").splitlines()):
+        if line.startswith("{"):
+            try:
+                rec = json.loads(line)
+            except ValueError:
+                continue
+            return {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
+                    "n_gpus": rec["n_gpus"], "steps": rec["steps"], "scaling": "strong",
+                    "acceptance": rec.get("acceptance"), "config": rec["config"]}
+    errf.seek(0)
+    tail = errf.read().decode(errors="replace").strip().splitlines()[-3:]
+    return {"error": "tiled leg exited with code %s" % proc.returncode, "stderr_tail": tail}
+
+
 def measured_traffic(kernel_prefix, workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
@@ -298,6 +355,10 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the barrier / MAX-reduce (gloo: rehearsal "
                          "of the multi-process path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--no-tiled-leg", action="store_true",
+                    help="N > 1, ensemble mode: skip the config-4 leg (one chain tiled over the "
+                         "same GPUs, reported as `config4_tiled` beside the ensemble `value`)")
+    ap.add_argument("--wait-stdin", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -309,6 +370,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    if args.wait_stdin:
+        import torch  # noqa: F401  (paged in while waiting; importing does not touch the GPU)
+        if not sys.stdin.readline().strip():
+            return                                      # the parent went away: nothing to do
+    leg = None
+    if world > 1:
+        # rank 0's CPU baselines and the extra legs belong to the N = 1 line only
+        args.no_cpu = True
+        args.no_extras = True
+        if (args.mode == "ensemble" and not args.dry_run and not args.no_tiled_leg
+                and os.environ.get("D3D_BENCH_TILED_LEG", "1") != "0"):
+            leg = start_tiled_leg(args, rank)
 
     dist = None
     torch = None
@@ -580,6 +654,14 @@ def main():
                       "contributions array) on config 1, 32x16x16 / 9x9" % (fn, fsecs)}
 
     eng.close()
+    if leg is not None:
+        # the ensemble measurement is over and this rank's context is closed: let the
+        # children run config 4 on the same GPUs
+        rec = finish_tiled_leg(leg, rank)
+        if rank == 0:
+            if "value" in rec:
+                rec["speedup_vs_one_gpu"] = round(rec["value"] / (value / world), 3)
+            out["config4_tiled"] = rec
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -324,3 +324,31 @@ def test_two_gloo_ranks_on_one_gpu_are_bit_identical(tmp_path):
         m = live[y0:y1, x0:x1]
         np.testing.assert_array_equal(np.load(tmp_path / ("params_%d.npy" % r))[m],
                                       ref_params[y0:y1, x0:x1][m])
+
+
+def test_bench_two_ranks_report_the_tiled_leg():
+    """`bench.py --gpus 2` (no launcher; gloo, both ranks on this one GPU): the contract line
+    is the ensemble's, and the config-4 leg -- one chain tiled over the same ranks, run by
+    child processes the ranks started before touching the GPU -- arrives as
+    `config4_tiled`; rank 0's CPU baselines stay out of an N > 1 line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+                        "--backend", "gloo", "--workload", "c2_64x64x64", "--steps", "2",
+                        "--warmup", "1", "--conv-iters", "2"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert "cpu_baseline" not in rec
+    leg = rec["config4_tiled"]
+    assert "error" not in leg, leg
+    assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0
+    assert "tiled 2x1" in leg["config"]["parallelism"]
+    assert 0.0 < leg["acceptance"] < 1.0
