@@ -327,7 +327,9 @@ def beyond_mall_leg(args, local_rank, fs):
         gbs = bytes_per_launch / (us * 1e-6) / 1e9
         return {"kernel": "k_mh_ws, 300x300x256 cube (working set 369 MB > 256 MB MALL)",
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(gbs / HBM_PEAK_GBS, 4),
+                # (the committed profile's command runs this leg too: same file, same run)
+                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 4,", args.workload),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
                 "launches": ncol * steps, "residual_written_every": eng.mh_layers(),
                 "value": round(steps * H * W / (ms * 1e-3), 1), "unit_value": "spaxel-updates/s"}
@@ -483,7 +485,7 @@ def main():
     roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, false,", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload),
                 "bytes_per_launch": bytes_per_sweep // ncol,
                 "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
                 # `achieved` prices the 24 B per window voxel of SURVEY 8(d) (read residual,
@@ -602,7 +604,7 @@ def main():
                 "bytes_per_launch": bytes_per_sweep * 2 // 3 // ncol,
                 "avg_launch_us": round(u_us, 2), "achieved": round(u_gbs, 1),
                 "frac": round(u_gbs / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, true,", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, true, 4, 2, 2,", args.workload),
                 "note": "extra: reference default variance=None (one constant); not `value`"}
 
     if rank == 0 and not args.no_extras:

@@ -53,6 +53,30 @@ for s in stats:
         row["l2_hit"] = h / (h + m) if h + m else None
     rows.append(row)
 
+# k_mh_ws is one kernel per number of pending layers (last template argument): the
+# colour classes of a sweep cycle through them, so the figure that compares with
+# bench.py's launch average is the launch-weighted mean over the family.
+families = collections.OrderedDict()
+for r in rows:
+    if r["kernel"].startswith("d3d::k_mh_ws<") and r["kernel"].count(",") == 5:
+        families.setdefault(r["kernel"].rsplit(",", 1)[0] + ", *>", []).append(r)
+variants = {}
+for fam, members in families.items():
+    calls = sum(m["calls"] for m in members)
+    agg = {"kernel": fam, "calls": calls,
+           "avg_us": sum(m["avg_us"] * m["calls"] for m in members) / calls,
+           "min_us": min(m["min_us"] for m in members), "max_us": max(m["max_us"] for m in members),
+           "pct": sum(m["pct"] for m in members)}
+    if all("hbm_MB" in m for m in members):
+        for key in ("fetch_MB", "write_MB", "hbm_MB"):
+            agg[key] = sum(m[key] * m["calls"] for m in members) / calls
+        for m in members:
+            variants[m["kernel"]] = traffic.pop(m["kernel"])
+        traffic[fam] = agg["hbm_MB"] * 1e6
+    if all(m.get("l2_hit") is not None for m in members):
+        agg["l2_hit"] = sum(m["l2_hit"] * m["calls"] for m in members) / calls
+    rows.insert(rows.index(members[0]), agg)
+
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as fh:
     fh.write(open(os.path.join(src, "trace_kernel_stats.csv")).read())
 with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
@@ -60,7 +84,9 @@ with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
     fh.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 "
              "--no-cpu --conv-iters 10` (+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
              "`--pmc TCC_HIT_sum TCC_MISS_sum` passes)\n\n")
-    fh.write("HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB.\n\n")
+    fh.write("HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB.  "
+             "`k_mh_ws<..., *>` rows: launch-weighted mean over the kernel's pending-layer variants "
+             "(last template argument), the figure bench.py's `avg_launch_us` compares with.\n\n")
     fh.write("| kernel | calls | avg us | min us | max us | % | fetch MB | write MB | HBM MB | L2 hit |\n")
     fh.write("|---|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
@@ -74,6 +100,7 @@ with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
         p = os.path.join(src, name)
         if os.path.exists(p):
             fh.write("\n`%s`:\n\n```\n%s```\n" % (name, open(p).read()))
-json.dump({"tag": tag, "workload": "c3_300x300x128", "hbm_bytes_per_launch": traffic},
+json.dump({"tag": tag, "workload": "c3_300x300x128", "hbm_bytes_per_launch": traffic,
+           "hbm_bytes_per_launch_variants": variants},
           open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print(open(os.path.join(dst, "%s_summary.md" % tag)).read()[:3000])
