@@ -1,7 +1,7 @@
 """Round-2 exploration: chain tolerance on well-identified functionals (C1)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deconv3d_amd import _lib
 from oracle import deconv3d_oracle as O

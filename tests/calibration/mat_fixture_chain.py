@@ -1,7 +1,7 @@
 """Round-2 exploration on the GPU box: statistics that calibrate the science tests."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import deconv3d_amd as d3d
 from deconv3d_amd import _lib

@@ -67,6 +67,22 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+    # ... nor do the tools; at the top level only bench.py (inside its cpu_baseline legs)
+    # and __graft_entry__.smoke() may
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for m in re.finditer(r"^(\s*)from oracle import", bench, re.M):
+        assert m.group(1), "bench.py imports the oracle at module level"
+        head = bench[:m.start()].rsplit("\ndef ", 1)[1].split("(")[0]
+        assert head.startswith("cpu_baseline"), head
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for m in re.finditer(r"^(\s*)from oracle import", entry, re.M):
+        head = entry[:m.start()].rsplit("\ndef ", 1)[1].split("(")[0]
+        assert m.group(1) and head == "smoke", head
 
 
 def test_c_abi_argument_errors_have_messages():
