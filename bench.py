@@ -384,7 +384,10 @@ def main():
         args.no_extras = True
         if (args.mode == "ensemble" and not args.dry_run and not args.no_tiled_leg
                 and os.environ.get("D3D_BENCH_TILED_LEG", "1") != "0"):
-            leg = start_tiled_leg(args, rank)
+            try:
+                leg = start_tiled_leg(args, rank)
+            except OSError as e:                        # the leg is an extra: never fatal
+                sys.stderr.write("bench.py: config-4 leg not started: %s\n" % e)
 
     dist = None
     torch = None
@@ -659,7 +662,11 @@ def main():
     if leg is not None:
         # the ensemble measurement is over and this rank's context is closed: let the
         # children run config 4 on the same GPUs
-        rec = finish_tiled_leg(leg, rank)
+        try:
+            rec = finish_tiled_leg(leg, rank)
+        except Exception as e:                          # the leg is an extra: never fatal
+            leg[0].kill()
+            rec = {"error": "tiled leg: %s: %s" % (type(e).__name__, e)}
         if rank == 0:
             if "value" in rec:
                 rec["speedup_vs_one_gpu"] = round(rec["value"] / (value / world), 3)
