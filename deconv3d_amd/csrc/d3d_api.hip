@@ -890,7 +890,9 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
     // (with several layers most launches only read: two positions in flight pay at
-    // full size, 43.3 -> 42.6 us per colour.  Round 2, for launches that do not fill the
+    // full size, 43.3 -> 42.6 us per colour; chosen per kind of launch instead -- four for
+    // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
+    // against 40.8 with two for both.  Round 2, for launches that do not fill the
     // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
     // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); FIFTEEN
     // streaming wavefronts per window instead of four (k_mh_ws<960>) helped 128-channel
