@@ -2586,7 +2586,6 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     if (item >= F.items) return;
     const int4 ent = F.ent[item];  // {y, x, real, colour ordinal}
     const int k = ent.w;
-    const int4 col = F.col[k];     // {first ticket, cy, cx, -}
     MHWsItem I;
     I.y = ent.x;
     I.x = ent.y;
