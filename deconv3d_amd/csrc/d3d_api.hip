@@ -170,6 +170,7 @@ struct d3d_ctx {
     // not been written into SLOT_ERR yet (k_mh_ws applies up to mh_layers of them)
     int lay_n = 0, lay_cy[3] = {-1, -1, -1}, lay_cx[3] = {-1, -1, -1}, lay_g[3] = {0, 0, 0};
     int mh_layers = 2;            // pending layers in use by the first part (d3d_mh_layers)
+    int mh_zigzag = 1;            // D3D_MH_ZIGZAG=0|1: odd colour ordinals walk windows / work lists backwards (MHArgs::rev)
     int mh_layers_cfg = 2;        // D3D_MH_LAYERS=1|2|3; small cubes fall back to 1 unless it is set
     bool mh_layers_forced = false;
     // dataflow kernel (k_mh_flow): one launch per sweep
@@ -757,6 +758,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.dlog = c->dlog;
     P.accepted = c->accepted;
     P.spx = c->spx;
+    P.rev = 0;
     for (int k = 0; k < 3; ++k) {
         P.min_b[k] = c->min_b[k];
         P.max_b[k] = c->max_b[k];
@@ -931,6 +933,7 @@ int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
     HIP_TRY(hipMemsetAsync(c->flow_state, 0, c->flow_state_bytes, c->stream));
     d3d::MHArgs P;
     fill_mh_args(c, P);
+    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
     d3d::MHFlow F;
     F.ent = c->flow_ent;
     F.col = c->flow_col;
@@ -970,6 +973,7 @@ int launch_mh_pair_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHPair &F, uin
 int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
     d3d::MHArgs P;
     fill_mh_args(c, P);
+    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
     d3d::MHPair F;
     F.ent = c->flow_ent;
     F.lat = c->flow_lat;
@@ -1082,6 +1086,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
     if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
+    if (const char *e = getenv("D3D_MH_ZIGZAG")) c->mh_zigzag = atoi(e) != 0;
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
     // other MH kernels keep one layer
@@ -1142,6 +1147,7 @@ int build_colour_lists(d3d_ctx *c) {
         pt.real.assign(ncol, 0);
         const bool empty = pt.y1 <= pt.y0 || pt.x1 <= pt.x0;
         int most = 0;
+        int ord = 0;  // ordinal of the colour among the part's active ones
         for (int cy = 0; cy < c->fh; ++cy)
             for (int cx = 0; cx < c->fw; ++cx) {
                 const int col = cy * c->fw + cx;
@@ -1165,6 +1171,17 @@ int build_colour_lists(d3d_ctx *c) {
                                              c->h_mask[(size_t)y * c->W + x];
                         if (!is_real) list.push_back(make_int4(y, x, 0, 0));
                     }
+                // Zig-zag over the cube as well: a launch of more workgroups than the chip
+                // holds runs them in list order, so every other colour starts where its
+                // predecessor ended -- on the lines still in the Infinity Cache.  (Windows of
+                // one colour are independent: the order changes no result.)
+                if (pt.real[col] > 0) {
+                    if (c->mh_zigzag && (ord & 1)) {
+                        std::reverse(list.begin() + pt.off[col], list.begin() + pt.off[col] + pt.real[col]);
+                        std::reverse(list.begin() + pt.off[col] + pt.real[col], list.end());
+                    }
+                    ++ord;
+                }
                 most = std::max(most, (int)list.size() - pt.off[col]);
             }
         pt.off[ncol] = (int)list.size();
@@ -2038,6 +2055,7 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         d3d::MHArgs P;
         fill_mh_args(c, P);
         P.spx = c->spx + pt.off[col];
+        P.rev = (c->mh_zigzag && (ka & 1)) ? 1 : 0;
         if (deferred) {
             // real + virtual positions: the windows of this launch tile the domain
             const int n_all = pt.off[col + 1] - pt.off[col];
@@ -2320,6 +2338,9 @@ int d3d_mh_colour(d3d_ctx *c, int colour, int sweep) {
         d3d::MHArgs P;
         fill_mh_args(c, P);
         P.spx = c->spx + pt.off[colour];
+        int ord = 0;  // the colour's ordinal among the part's active ones, as in run_part
+        for (int col = 0; col < colour; ++col) ord += pt.real[col] > 0;
+        P.rev = (c->mh_zigzag && (ord & 1)) ? 1 : 0;
         int rc = launch_mh(c, P, (unsigned)n_real, (uint32_t)sweep + c->sweep_origin);
         if (rc) return rc;
     }

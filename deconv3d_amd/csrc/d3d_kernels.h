@@ -1535,6 +1535,14 @@ struct MHArgs {
     // layers" below); prev_cy / prev_cx / Gprev above describe the only layer for
     // the kernels that keep a single one
     int n_lay, write_back;
+    // Zig-zag: every other colour class of a part walks its window positions from the
+    // last to the first (k_mh, k_mh_defer, k_mh_ws: this launch's direction; k_mh_flow,
+    // k_mh_pair: zig-zag enabled, the direction follows the item's colour ordinal).  A
+    // colour's window is its predecessor's shifted by one column: read backwards, it meets
+    // the lines the predecessor touched LAST first, still in the Infinity Cache when the
+    // cube's working set exceeds it (300x300x256: 96.8 -> 83.7 us per launch).  The window
+    // sums are then accumulated in that order, in every kernel alike.
+    int rev;
     int lay_cy[3], lay_cx[3];
     const double *lay_G[3];
     int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
@@ -1879,10 +1887,11 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     if constexpr (MAXIT > 0) {
 #pragma unroll
         for (int it = 0; it < NREG; ++it) {
-            const int p = g + it * G;
+            const int pw = g + it * G;
+            const int p = P.rev ? P.npos - 1 - pw : pw;
             const int dy = p / P.fw, dx = p - dy * P.fw;
             const int yy = y + dy - fhh, xx = x + dx - fhw;
-            const bool ok = active && p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            const bool ok = active && pw < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             double2 e = make_double2(0.0, 0.0), v = e;
             double f = 0.0;
             if (ok) {
@@ -1896,7 +1905,8 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
         }
     } else {
         if (active) {
-            for (int p = g; p < P.npos; p += G) {
+            for (int pw = g; pw < P.npos; pw += G) {
+                const int p = P.rev ? P.npos - 1 - pw : pw;
                 const int dy = p / P.fw, dx = p - dy * P.fw;
                 const int yy = y + dy - fhh, xx = x + dx - fhw;
                 if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
@@ -1929,10 +1939,11 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
     if constexpr (MAXIT > 0) {
 #pragma unroll
         for (int it = 0; it < NREG; ++it) {
-            const int p = g + it * G;
+            const int pw = g + it * G;
+            const int p = P.rev ? P.npos - 1 - pw : pw;
             const int dy = p / P.fw, dx = p - dy * P.fw;
             const int yy = y + dy - fhh, xx = x + dx - fhw;
-            const bool ok = p < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
+            const bool ok = pw < P.npos && yy >= 0 && yy < P.H && xx >= 0 && xx < P.W;
             if (ok) {
                 const long idx = ((long)yy * P.W + xx) * Dp + 2 * zl;
                 const double f = S.fsf[p];
@@ -1943,7 +1954,8 @@ __global__ __launch_bounds__(NT) void k_mh(MHArgs P, uint32_t sweep) {
             }
         }
     } else {
-        for (int p = g; p < P.npos; p += G) {
+        for (int pw = g; pw < P.npos; pw += G) {
+            const int p = P.rev ? P.npos - 1 - pw : pw;
             const int dy = p / P.fw, dx = p - dy * P.fw;
             const int yy = y + dy - fhh, xx = x + dx - fhw;
             if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
@@ -2033,7 +2045,8 @@ __global__ __launch_bounds__(NT) void k_mh_defer(MHArgs P, uint32_t sweep) {
     double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
     if (active) {
 #pragma unroll 4
-        for (int p = g; p < P.npos; p += G) {
+        for (int pw = g; pw < P.npos; pw += G) {
+            const int p = P.rev ? P.npos - 1 - pw : pw;
             const int vox = S.pos[3 * p + 0];
             if (vox < 0) continue;
             const int tap = S.pos[3 * p + 1];
@@ -2107,6 +2120,7 @@ __host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int 
 struct MHWsItem {
     int y, x, real;
     int n_lay, write_back;
+    int rev;  // window positions last to first (MHArgs::rev)
     int lay_cy[MH_LAYERS], lay_cx[MH_LAYERS];  // colour class of each pending layer
     // the <= 2 x 2 spaxels of layer j that cover this window (-1 = none).  Only ever
     // indexed with compile-time constants: a dynamic index would put it in scratch.
@@ -2119,6 +2133,7 @@ struct MHWsItem {
 __device__ __forceinline__ void mh_ws_layers_from_args(const MHArgs &P, MHWsItem &I) {
     I.n_lay = P.n_lay;
     I.write_back = P.write_back;
+    I.rev = P.rev;
 #pragma unroll
     for (int j = 0; j < MH_LAYERS; ++j) {
         I.lay_cy[j] = P.lay_cy[j];
@@ -2280,8 +2295,9 @@ __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &
     if (tid >= NS || g >= G) return;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int p = g + u * G;
-        if (p < P.npos) {
+        const int pw = g + u * G;
+        if (pw < P.npos) {
+            const int p = I.rev ? P.npos - 1 - pw : pw;
             const int dy = p / P.fw, dx = p - dy * P.fw;
             const int yy = I.y + dy - fhh, xx = I.x + dx - fhw;
             const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
@@ -2339,8 +2355,9 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             auto issue = [&](int p0, int (&vox)[U], double2 (&e)[U], double2 (&v)[U]) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int p = p0 + u * G;
-                    vox[u] = (p < P.npos) ? S.pos[ROW * p] : -1;
+                    const int pw = p0 + u * G;
+                    const int p = I.rev ? P.npos - 1 - pw : pw;
+                    vox[u] = (pw < P.npos) ? S.pos[ROW * p] : -1;
                     const long idx = (long)max(vox[u], 0) * Dp + 2 * zl;
                     if (COH) {
                         cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
@@ -2356,7 +2373,8 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     if (vox[u] < 0) continue;
-                    const int p = p0 + u * G;
+                    const int pw = p0 + u * G;
+                    const int p = I.rev ? P.npos - 1 - pw : pw;
                     const long idx = (long)vox[u] * Dp + 2 * zl;
                     // the pending layers, oldest first: e <- e + f G of each
                     bool touched = false;
@@ -2605,6 +2623,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
     // one pending layer (the previous colour), written back by every item
     I.n_lay = prev_cy >= 0 ? 1 : 0;
     I.write_back = 1;
+    I.rev = P.rev ? (k & 1) : 0;  // P.rev: zig-zag enabled; k: the colour's ordinal
 #pragma unroll
     for (int j = 0; j < MH_LAYERS; ++j) {
         I.lay_cy[j] = prev_cy;
@@ -2722,6 +2741,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     I.real = ent.z;
     // pending layers: those of the launch arguments, and for a B item colour A on top
     mh_ws_layers_from_args(P, I);
+    I.rev = P.rev ? ((F.ka + (is_b ? 1 : 0)) & 1) : 0;  // P.rev: zig-zag enabled
     bool ok = true;
     if (is_b) {
         // (the host fuses a pair only when exactly ONE layer is pending: static index 1)
