@@ -170,6 +170,7 @@ struct d3d_ctx {
     // not been written into SLOT_ERR yet (k_mh_ws applies up to mh_layers of them)
     int lay_n = 0, lay_cy[3] = {-1, -1, -1}, lay_cx[3] = {-1, -1, -1}, lay_g[3] = {0, 0, 0};
     int mh_layers = 2;            // pending layers in use by the first part (d3d_mh_layers)
+    bool mh_nt_ivar = false;      // 1/variance loads non-temporal: residual + 1/variance exceed the Infinity Cache (D3D_MH_NT_IVAR)
     int mh_zigzag = 1;            // D3D_MH_ZIGZAG=0|1: odd colour ordinals walk windows / work lists backwards (MHArgs::rev)
     int mh_layers_cfg = 2;        // D3D_MH_LAYERS=1|2|3; small cubes fall back to 1 unless it is set
     bool mh_layers_forced = false;
@@ -850,28 +851,28 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV, int U, int M, int K>
+template <bool UV, int U, int M, int K, bool NTV = false>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
     // (the number of pending layers as a template constant: see k_mh_ws)
     switch (P.n_lay <= M ? P.n_lay : -1) {
         case 0:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0>), dim3(grid),
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0, NTV>), dim3(grid),
                                dim3(NS + 64), lds, c->stream, P, sweep);
             break;
         case 1:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1>), dim3(grid),
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1, NTV>), dim3(grid),
                                dim3(NS + 64), lds, c->stream, P, sweep);
             break;
         case 2:
             if constexpr (M >= 2)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2>), dim3(grid),
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2, NTV>), dim3(grid),
                                    dim3(NS + 64), lds, c->stream, P, sweep);
             break;
         case 3:
             if constexpr (M >= 3)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3>), dim3(grid),
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3, NTV>), dim3(grid),
                                    dim3(NS + 64), lds, c->stream, P, sweep);
             break;
         default:
@@ -900,6 +901,18 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // streaming wavefronts per window instead of four (k_mh_ws<960>) helped 128-channel
     // tile parts, 4.13 -> 3.41 ms per sweep for an 8x1 rank, but cost shallow cubes,
     // 9.9 -> 12.2 us per launch at 32x16x16, and another grouping of the window sums)
+    // (1/variance with the non-temporal hint when the context's working set exceeds the
+    // Infinity Cache: mh_load_ivar; only the chip-filling launches have the variant)
+    if constexpr (!UV) {
+        if (c->mh_nt_ivar && !small) {
+            if (c->mh_layers >= 3) return launch_mh_ws_um<UV, 2, 3, 2, true>(c, P, grid, sweep);
+            if (c->mh_layers == 2) {
+                if (c->Dp > 160) return launch_mh_ws_um<UV, 2, 2, 4, true>(c, P, grid, sweep);
+                return launch_mh_ws_um<UV, 2, 2, 2, true>(c, P, grid, sweep);
+            }
+            return launch_mh_ws_um<UV, 1, 1, 4, true>(c, P, grid, sweep);
+        }
+    }
     if (c->mh_layers >= 3) {  // Dp <= 160
         if (small) return launch_mh_ws_um<UV, 4, 3, 2>(c, P, grid, sweep);
         return launch_mh_ws_um<UV, 2, 3, 2>(c, P, grid, sweep);
@@ -1087,6 +1100,10 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
     if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
     if (const char *e = getenv("D3D_MH_ZIGZAG")) c->mh_zigzag = atoi(e) != 0;
+    // measured crossover on MI355X (256 MiB Infinity Cache): 276 / 323 MB +1 %, 369 MB +6 %,
+    // 230 MB -7 % (tools/mh_sizes.py)
+    c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6;
+    if (const char *e = getenv("D3D_MH_NT_IVAR")) c->mh_nt_ivar = atoi(e) != 0;
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
     // other MH kernels keep one layer

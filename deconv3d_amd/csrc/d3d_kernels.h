@@ -2270,6 +2270,22 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
 // (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
 // COHG: only the G row this item leaves is published coherently (k_mh_pair: the other
 // colour class of the same launch reads it; the residual is handed over by nobody).
+// NTV: the 1/variance stream with the non-temporal hint.  When residual + 1/variance
+// exceed the Infinity Cache, the read-only half should not compete for it with the half
+// that the next colour class re-reads AND rewrites (300x300x256: 83.7 -> 78.9 us per
+// launch, 600x600x128: 176 -> 164); when both fit, the hint costs (300x300x128: 40.7 ->
+// 43.3 us).  The host chooses per context (d3d_ctx::mh_nt_ivar); same bytes, same results.
+typedef double d3d_v2d __attribute__((ext_vector_type(2)));
+template <bool NTV>
+__device__ __forceinline__ double2 mh_load_ivar(const double *p) {
+    if constexpr (NTV) {
+        const d3d_v2d t = __builtin_nontemporal_load(reinterpret_cast<const d3d_v2d *>(p));
+        return make_double2(t.x, t.y);
+    } else {
+        return *reinterpret_cast<const double2 *>(p);
+    }
+}
+
 template <int U>
 struct MHPre {
     int vox[U];
@@ -2279,7 +2295,7 @@ struct MHPre {
 // The loads of the first window round of a streaming thread (positions g + u G), issued
 // before the workgroup's setup: S.pos is not built yet, so the voxel index is computed
 // here -- the same expression as mh_ws_table's.
-template <int NS, bool UV, int U>
+template <int NS, bool UV, int U, bool NTV = false>
 __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &I, MHPre<U> &R) {
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp;
@@ -2305,11 +2321,11 @@ __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &
         }
         const long idx = (long)max(R.vox[u], 0) * Dp + 2 * zl;
         R.e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
-        if (!UV) R.v[u] = *reinterpret_cast<const double2 *>(P.ivar + idx);
+        if (!UV) R.v[u] = mh_load_ivar<NTV>(P.ivar + idx);
     }
 }
 
-template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false>
+template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false, bool NTV = false>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                           uint32_t sweep, long stamp_at,
                                           const MHPre<U> *pre = nullptr) {
@@ -2366,7 +2382,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                         e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
                     }
                     v[u] = vu;
-                    if (!UV) v[u] = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                    if (!UV) v[u] = mh_load_ivar<NTV>(P.ivar + idx);
                 }
             };
             auto consume = [&](int p0, int (&vox)[U], double2 (&e)[U], double2 (&v)[U]) {
@@ -2484,7 +2500,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 // As a compile-time constant the "layer j is live" tests of the setup fold away -- and with
 // them a store at a run-time index that kept the item's small arrays, and three dependent
 // scratch round trips, in every workgroup's setup.
-template <int NS, bool UV, int U, int M, int K, int NL = -1>
+template <int NS, bool UV, int U, int M, int K, int NL = -1, bool NTV = false>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
@@ -2503,7 +2519,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         return;
     }
     MHPre<U> pre;
-    mh_ws_prefetch<NS, UV, U>(P, I, pre);  // the window's first loads fly during the setup
+    mh_ws_prefetch<NS, UV, U, NTV>(P, I, pre);  // the window's first loads fly during the setup
     mh_ws_preds<M>(P, I);
     MHGpRegs<M, K> gv;
     mh_ws_gp_load<M, K, false>(P, I, NT, gv);  // in flight while the table is computed
@@ -2511,7 +2527,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
-    mh_ws_run<NS, UV, false, U, M, false, true>(P, S, I, sweep, blockIdx.x, &pre);
+    mh_ws_run<NS, UV, false, U, M, false, true, NTV>(P, S, I, sweep, blockIdx.x, &pre);
 }
 
 // ---- one launch per sweep: dataflow over the colour classes ----------------

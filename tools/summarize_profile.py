@@ -53,13 +53,15 @@ for s in stats:
         row["l2_hit"] = h / (h + m) if h + m else None
     rows.append(row)
 
-# k_mh_ws is one kernel per number of pending layers (last template argument): the
+# k_mh_ws is one kernel per number of pending layers (sixth template argument): the
 # colour classes of a sweep cycle through them, so the figure that compares with
 # bench.py's launch average is the launch-weighted mean over the family.
 families = collections.OrderedDict()
 for r in rows:
-    if r["kernel"].startswith("d3d::k_mh_ws<") and r["kernel"].count(",") == 5:
-        families.setdefault(r["kernel"].rsplit(",", 1)[0] + ", *>", []).append(r)
+    if r["kernel"].startswith("d3d::k_mh_ws<") and r["kernel"].count(",") == 6:
+        args = r["kernel"][len("d3d::k_mh_ws<"):-1].split(", ")
+        args[5] = "*"                      # the pending-layer count
+        families.setdefault("d3d::k_mh_ws<" + ", ".join(args) + ">", []).append(r)
 variants = {}
 for fam, members in families.items():
     calls = sum(m["calls"] for m in members)
@@ -86,7 +88,7 @@ with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
              "`--pmc TCC_HIT_sum TCC_MISS_sum` passes)\n\n")
     fh.write("HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB.  "
              "`k_mh_ws<..., *>` rows: launch-weighted mean over the kernel's pending-layer variants "
-             "(last template argument), the figure bench.py's `avg_launch_us` compares with.\n\n")
+             "(sixth template argument; the seventh: 1/variance loads with the non-temporal hint), the figure bench.py's `avg_launch_us` compares with.\n\n")
     fh.write("| kernel | calls | avg us | min us | max us | % | fetch MB | write MB | HBM MB | L2 hit |\n")
     fh.write("|---|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
