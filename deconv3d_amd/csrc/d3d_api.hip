@@ -1191,9 +1191,13 @@ int build_colour_lists(d3d_ctx *c) {
                 // Zig-zag over the cube as well: a launch of more workgroups than the chip
                 // holds runs them in list order, so every other colour starts where its
                 // predecessor ended -- on the lines still in the Infinity Cache.  (Windows of
-                // one colour are independent: the order changes no result.)
+                // one colour are independent: the order changes no result.)  Only then: in a
+                // launch that is resident at once, workgroup i of every colour runs on the same
+                // XCD, whose L2 still holds its predecessor's window (64^3: 12.3 vs 12.6 us per
+                // launch with the lists reversed).
                 if (pt.real[col] > 0) {
-                    if (c->mh_zigzag && (ord & 1)) {
+                    const int n_all_col = (int)list.size() - pt.off[col];
+                    if (c->mh_zigzag && (ord & 1) && n_all_col > c->flow_grid) {
                         std::reverse(list.begin() + pt.off[col], list.begin() + pt.off[col] + pt.real[col]);
                         std::reverse(list.begin() + pt.off[col] + pt.real[col], list.end());
                     }

@@ -2163,14 +2163,16 @@ __device__ __forceinline__ void mh_ws_preds(const MHArgs &P, MHWsItem &I) {
 // needs mh_ws_preds.  Table row of position p: [0] local spaxel index of the voxel
 // column (-1 = outside the launch's domain); [1+j] for layer j: tap index of that layer's
 // update there | which of its <= 4 staged G rows << 16, or -1 = none.
+// tap0: the caller's early load of P.fsf[threadIdx.x] (k_mh_ws issues it before the window
+// prefetch, so that the table does not queue behind it), or NULL.
 template <int M>
 __device__ __forceinline__ void mh_ws_table(const MHArgs &P, const MHShared &S, const MHWsItem &I,
-                                            int NT) {
+                                            int NT, const double *tap0 = nullptr) {
     constexpr int ROW = 1 + M;
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
     const int y = I.y, x = I.x;
     for (int p = threadIdx.x; p < P.npos; p += NT) {
-        S.fsf[p] = P.fsf[p];
+        S.fsf[p] = (tap0 && p == (int)threadIdx.x) ? *tap0 : P.fsf[p];
         const int dy = p / P.fw, dx = p - dy * P.fw;
         const int yy = y + dy - fhh, xx = x + dx - fhw;
         const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
@@ -2518,12 +2520,16 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
         mh_ws_zero_row<false>(P, I);
         return;
     }
-    MHPre<U> pre;
-    mh_ws_prefetch<NS, UV, U, NTV>(P, I, pre);  // the window's first loads fly during the setup
+    // Loads in the order the setup needs them -- a wavefront's loads return in order: the
+    // pending G rows and the taps first, THEN the window's first round, which flies during
+    // the rest of the setup instead of holding it up.
     mh_ws_preds<M>(P, I);
     MHGpRegs<M, K> gv;
-    mh_ws_gp_load<M, K, false>(P, I, NT, gv);  // in flight while the table is computed
-    mh_ws_table<M>(P, S, I, NT);
+    mh_ws_gp_load<M, K, false>(P, I, NT, gv);
+    const double tap0 = ((int)threadIdx.x < P.npos) ? P.fsf[threadIdx.x] : 0.0;
+    MHPre<U> pre;
+    mh_ws_prefetch<NS, UV, U, NTV>(P, I, pre);
+    mh_ws_table<M>(P, S, I, NT, &tap0);
     mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
