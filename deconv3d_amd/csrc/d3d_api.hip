@@ -1102,7 +1102,9 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_MH_ZIGZAG")) c->mh_zigzag = atoi(e) != 0;
     // measured crossover on MI355X (256 MiB Infinity Cache): 276 / 323 MB +1 %, 369 MB +6 %,
     // 230 MB -7 % (tools/mh_sizes.py)
-    c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6;
+    // (the write-through residual stores of that variant address SLOT_ERR as a raw buffer: < 2 GiB)
+    c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6 &&
+                    8.0 * (double)c->Dp * (double)c->H * (double)c->W < 2147483648.0;
     if (const char *e = getenv("D3D_MH_NT_IVAR")) c->mh_nt_ivar = atoi(e) != 0;
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the

@@ -2272,7 +2272,8 @@ __device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &
 // (cdna_hip_programming.md, Guideline 16, the all-sc1 form).
 // COHG: only the G row this item leaves is published coherently (k_mh_pair: the other
 // colour class of the same launch reads it; the residual is handed over by nobody).
-// NTV: the 1/variance stream with the non-temporal hint.  When residual + 1/variance
+// NTV (cache policy of a context beyond the Infinity Cache): the 1/variance stream with the
+// non-temporal hint, and the residual stored write-through (mh_ws_run).  When residual + 1/variance
 // exceed the Infinity Cache, the read-only half should not compete for it with the half
 // that the next colour class re-reads AND rewrites (300x300x256: 83.7 -> 78.9 us per
 // launch, 600x600x128: 176 -> 164); when both fit, the hint costs (300x300x128: 40.7 ->
@@ -2359,7 +2360,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             union { double2 d; v4u i; } cv;
             const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                P.err, 0, COH ? (int)((long)P.H * P.W * Dp * 8) : 0, 0x00020000);
+                P.err, 0, (COH || NTV) ? (int)((long)P.H * P.W * Dp * 8) : 0, 0x00020000);
             // U window positions per round: all their loads are issued before the
             // first is consumed.  U = 1 when a launch fills the chip (the stream is at
             // the HBM peak; more requests in flight only add contention: 52.9 vs
@@ -2409,7 +2410,10 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                         }
                     }
                     if (touched && I.write_back) {
-                        if (COH) {
+                        // (NTV, a context beyond the Infinity Cache: write-through as well --
+                        // no dirty lines left for the end of the kernel to flush; 300x300x256
+                        // 79.4 -> 76.7 us per launch, nothing where everything fits)
+                        if (COH || NTV) {
                             cv.d = e[u];
                             __builtin_amdgcn_raw_buffer_store_b128(cv.i, err_rsrc, (int)(idx * 8), 0,
                                                                    16);
