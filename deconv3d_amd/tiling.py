@@ -39,8 +39,8 @@ dependent chain of fh*fw launches, and a launch that does not fill the chip cost
 ~17 us at 128 channels however few windows it holds.  One interior rank of an 8 x 1
 tiling of 300x300x128 computes 4.1 ms per sweep alone against 5.1 ms for the whole
 cube on one GPU: the tiled chain is the mode for a cube or a chain that must be SPLIT
-(or one much larger than 300x300: at 900x900x128 a rank of 8 x 1 computes 7.3 ms against
-49.4 ms for the whole cube, 6.8x); it does not make a 300x300 chain faster.  Row
+(or one much larger than 300x300: at 900x900x128 a rank of 8 x 1 computes 7.2 ms against
+45.7 ms for the whole cube, 6.3x); it does not make a 300x300 chain faster.  Row
 strips (N x 1: two phases) are the default layout; 2-D grids (four phases) are
 supported and exact.  The throughput mode across GPUs is the ensemble.
 
