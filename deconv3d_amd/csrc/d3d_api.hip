@@ -181,6 +181,7 @@ struct d3d_ctx {
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
     // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
     // monotonic ticket counter, so that nothing needs clearing between launches
+    int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)
     unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item
@@ -851,9 +852,8 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
     return 0;
 }
 
-template <bool UV, int U, int M, int K, bool NTV = false>
+template <bool UV, int U, int M, int K, bool NTV = false, int NS = 256>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    constexpr int NS = 256;
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
     // (the number of pending layers as a template constant: see k_mh_ws)
     switch (P.n_lay <= M ? P.n_lay : -1) {
@@ -897,10 +897,8 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
     // against 40.8 with two for both.  Round 2, for launches that do not fill the
     // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
-    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); FIFTEEN
-    // streaming wavefronts per window instead of four (k_mh_ws<960>) helped 128-channel
-    // tile parts, 4.13 -> 3.41 ms per sweep for an 8x1 rank, but cost shallow cubes,
-    // 9.9 -> 12.2 us per launch at 32x16x16, and another grouping of the window sums)
+    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); fifteen
+    // streaming wavefronts per window: see the 960-thread form below)
     // (1/variance with the non-temporal hint when the context's working set exceeds the
     // Infinity Cache: mh_load_ivar; only the chip-filling launches have the variant)
     if constexpr (!UV) {
@@ -925,6 +923,22 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
         if (small) return launch_mh_ws_um<UV, 4, 2, 2>(c, P, grid, sweep);
         return launch_mh_ws_um<UV, 2, 2, 2>(c, P, grid, sweep);
     }
+    // The small launches of a PARTITIONED context (tiles, d3d_set_parts) at 128 channels: a
+    // launch of at most one workgroup per CU is bound by how fast ONE workgroup gets through
+    // its window (121 positions through four wavefronts, ~1 us per round trip), so fifteen
+    // streaming wavefronts instead of four (k_mh_ws<960>, ONE position in flight per
+    // wavefront: 3.52 ms against 3.61 with two and 3.77 with four): an 8x1 rank of
+    // 300x300x128 4.18 -> 3.52 ms per sweep.  (What then bounds such a launch, by the phase
+    // stamps: setup 2.3 us, the prepare wavefront's proposal -> line -> LSF chain 6.4, the
+    // decision tail 4.5, the kernel boundary 2.4; a second prepare wavefront for the
+    // current line gained 1.5 %: not kept.)  Another grouping of the window sums than the 256-thread form
+    // (results agree to rounding, not bit for bit), hence only where nothing is compared bit for
+    // bit with another scheme: a given part always takes the same form, so a tiled chain and
+    // the single context given the same parts still agree to the last bit.  Shallow cubes lose
+    // (32 channels: 9.9 -> 12.2 us per launch).  D3D_MH_WIDE=0: off.
+    if (small && c->mh_wide && (c->tiled || !c->part_rects.empty()) && c->Dp == 128 &&
+        grid <= (unsigned)c->flow_grid / 4)
+        return launch_mh_ws_um<UV, 1, 1, 1, false, 960>(c, P, grid, sweep);
     if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
 }
@@ -1099,6 +1113,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
     if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
     if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
+    if (const char *e = getenv("D3D_MH_WIDE")) c->mh_wide = atoi(e);
     if (const char *e = getenv("D3D_MH_ZIGZAG")) c->mh_zigzag = atoi(e) != 0;
     // measured crossover on MI355X (256 MiB Infinity Cache): 276 / 323 MB +1 %, 369 MB +6 %,
     // 230 MB -7 % (tools/mh_sizes.py)
