@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("DECONV3D_HIP_LIB") or os.path.join(_HERE, "csrc", "li
 SYMBOLS = [
     "d3d_version", "d3d_source_hash", "d3d_last_error", "d3d_device_count",
     "d3d_ctx_create", "d3d_ctx_destroy", "d3d_ctx_set_stream", "d3d_sync",
+    "d3d_ctx_set_option", "d3d_ctx_get_option", "d3d_has_experiments",
     "d3d_timer_start", "d3d_timer_stop",
     "d3d_set_taps", "d3d_set_data", "d3d_set_params", "d3d_get_params",
     "d3d_build_clean", "d3d_convolve", "d3d_forward", "d3d_simulate", "d3d_residual",
@@ -80,6 +81,9 @@ def load():
     lib.d3d_ctx_destroy.argtypes = [ctx_p]
     lib.d3d_ctx_set_stream.argtypes = [ctx_p, C.c_void_p]
     lib.d3d_sync.argtypes = [ctx_p]
+    lib.d3d_ctx_set_option.argtypes = [ctx_p, C.c_char_p, C.c_long]
+    lib.d3d_ctx_get_option.argtypes = [ctx_p, C.c_char_p, C.POINTER(C.c_long)]
+    lib.d3d_has_experiments.restype = C.c_int
     lib.d3d_timer_start.argtypes = [ctx_p]
     lib.d3d_timer_stop.argtypes = [ctx_p, dbl_p]
     lib.d3d_set_taps.argtypes = [ctx_p, dbl_p, dbl_p, C.c_double]
@@ -136,7 +140,7 @@ def load():
     lib.d3d_apply_updates.argtypes = [ctx_p, C.c_int, dbl_p]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("d3d_version", "d3d_last_error", "d3d_source_hash"):
+        if name not in ("d3d_version", "d3d_last_error", "d3d_source_hash", "d3d_has_experiments"):
             fn.restype = C.c_int
     _lib = lib
     return lib
@@ -145,6 +149,11 @@ def load():
 def source_hash():
     """Hash of the sources the loaded binary was compiled from (csrc/Makefile)."""
     return load().d3d_source_hash().decode("ascii", "replace")
+
+
+def has_experiments():
+    """True when the library was built with `make EXPERIMENTS=1`."""
+    return bool(load().d3d_has_experiments())
 
 
 def comm_unique_id():
@@ -188,7 +197,10 @@ class Engine(object):
     Thin, typed mirror of the C ABI; arrays in the reference's layouts.
     """
 
-    def __init__(self, shape, fsf_shape, device=0):
+    def __init__(self, shape, fsf_shape, device=0, options=None):
+        """options: {key: int} passed to :meth:`set_option` (d3d_ctx_set_option) right
+        after the context exists -- per-context, unlike the D3D_<KEY> environment
+        defaults."""
         self._lib = load()
         self._ctx = C.c_void_p(None)
         D, H, W = [int(v) for v in shape]
@@ -197,6 +209,8 @@ class Engine(object):
         self.fsf_shape = (fh, fw)
         _check(self._lib.d3d_ctx_create(C.byref(self._ctx), int(device),
                                         D, H, W, fh, fw))
+        for key, value in (options or {}).items():
+            self.set_option(key, value)
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -217,6 +231,15 @@ class Engine(object):
         self.close()
 
     # -- plumbing ---------------------------------------------------------
+    def set_option(self, key, value):
+        """Per-context kernel selection switch (include/deconv3d_hip.h: d3d_ctx_set_option)."""
+        _check(self._lib.d3d_ctx_set_option(self._ctx, str(key).encode("ascii"), int(value)))
+
+    def get_option(self, key):
+        v = C.c_long(0)
+        _check(self._lib.d3d_ctx_get_option(self._ctx, str(key).encode("ascii"), C.byref(v)))
+        return v.value
+
     def set_stream(self, stream_handle):
         _check(self._lib.d3d_ctx_set_stream(self._ctx, C.c_void_p(stream_handle)))
 

@@ -1,33 +1,19 @@
 // C ABI of libdeconv3d_hip.so -- see include/deconv3d_hip.h.
-// Host-side context, device memory, launch geometry.  gfx950 only.
-#include <hip/hip_runtime.h>
-#include <rccl/rccl.h>  // types only: the library is dlopen()ed by d3d_comm_init
+// Host-side context, device memory, work lists, options, halo exchange.  gfx950 only.
+#include "d3d_ctx.h"
 
 #include <dlfcn.h>
 
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "../../include/deconv3d_hip.h"
-#include "d3d_kernels.h"
-#include "d3d_conv.h"
-
-#define D3D_VERSION 200  // 0.2.0
+#define D3D_VERSION 300  // 0.3.0
 #ifndef D3D_SOURCE_HASH
 #define D3D_SOURCE_HASH "unknown"
 #endif
 
 namespace {
-
 thread_local std::string g_err;
+}
 
+namespace d3dh {
 int fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
@@ -37,20 +23,12 @@ int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
+}  // namespace d3dh
 
-#define HIP_TRY(expr)                                                                   \
-    do {                                                                                \
-        hipError_t e_ = (expr);                                                         \
-        if (e_ != hipSuccess)                                                           \
-            return fail(D3D_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                        __FILE__, __LINE__);                                            \
-    } while (0)
+using d3dh::fail;
+using namespace d3dh;
 
-#define NEED(cond, code, ...) \
-    do {                      \
-        if (!(cond)) return fail(code, __VA_ARGS__); \
-    } while (0)
-
+namespace {
 // RCCL is loaded at run time (the library stays loadable without it, and a process
 // that already holds an RCCL -- torch's -- shares that one: same soname).
 struct RcclApi {
@@ -79,179 +57,9 @@ int next_pow2_ref(int depth) {
 
 }  // namespace
 
-struct d3d_ctx {
-    int device = 0;
-    int D = 0, H = 0, W = 0, fh = 0, fw = 0;
-    int Dp = 0, HL = 0, N = 0;
-    long HW = 0;
-    size_t cube_elems = 0;  // HW * Dp
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-
-    double *slot[D3D_SLOT_COUNT] = {};
-    double *stage = nullptr;   // D*HW doubles, host-layout staging
-    double *stage2 = nullptr;  // second staging (variance)
-    double *params = nullptr;  // HW*3
-    double *params_alt = nullptr;  // HW*3: parameter map of d3d_simulate (not the chain state)
-    uint8_t *mask = nullptr;   // HW
-    double *fsf = nullptr;     // fh*fw
-    int *lsf_shift = nullptr;
-    double *lsf_weight = nullptr;
-    int ntaps = 0;
-    double *dlog = nullptr;  // HW
-    double *hwbuf = nullptr; // HW scratch (chi2 map)
-    double *scal = nullptr;  // small device scalars (8 doubles)
-    unsigned long long *accepted = nullptr;
-    int4 *spx = nullptr;  // work lists per (part, colour): real spaxels first, then virtual ones
-    std::vector<int> colour_real;  // fh*fw: number of real spaxels of each colour (all parts)
-    size_t spx_cap = 0;
-    // A PART is a rectangle of spaxels updated together: sweep = for every phase, for
-    // every part of the phase, for every colour class, one launch (lib/run.py:553-560
-    // declares the scan order overridable).  An unpartitioned context has one part,
-    // the whole cube (a tile: its owned rectangle).  The DOMAIN of a part is the set
-    // of cells its windows touch.
-    struct Part {
-        int y0 = 0, y1 = 0, x0 = 0, x1 = 0;      // spaxels (local)
-        int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;  // domain (local)
-        int phase = 0;
-        int layers = 1;                          // pending layers in use
-        std::vector<int> off;                    // fh*fw + 1: start of each colour's list in spx
-        std::vector<int> real;                   // fh*fw: real spaxels of each colour
-    };
-    std::vector<Part> parts;
-    std::vector<int4> part_rects;  // as given to d3d_set_parts ({y0,y1,x0,x1}; .phase apart)
-    std::vector<int> part_phase;
-    int n_phases = 1;
-    int pend_part = -1;            // part the pending layers belong to
-    // halo plans (tiled chains): per plan a list of rectangle copies to / from peers
-    struct HaloEntry {
-        int peer = 0, what = 0;                   // what: 0 = SLOT_ERR cells, 1 = parameter map
-        int sy0 = 0, sy1 = 0, sx0 = 0, sx1 = 0;  // rectangle sent (local), empty when sy1 <= sy0
-        int ry0 = 0, ry1 = 0, rx0 = 0, rx1 = 0;  // rectangle received (local)
-        size_t send_off = 0, send_n = 0, recv_off = 0, recv_n = 0;  // in doubles
-    };
-    std::vector<std::vector<HaloEntry>> plans;
-    double *halo_send = nullptr, *halo_recv = nullptr;
-    size_t halo_send_cap = 0, halo_recv_cap = 0;
-    // asynchronous chain streaming (lib/run.py:447-451 chain[i] = parameters, :428-432):
-    // at a saved sweep the compute stream snapshots parameters + log ratios device to
-    // device (microseconds), a COPY stream moves the snapshot to a pinned host buffer,
-    // and the host thread copies it into the caller's (pageable) chain while the GPU
-    // runs on -- STREAM_NB snapshots may be in flight
-    static constexpr int STREAM_NB = 4;
-    hipStream_t copy_stream = nullptr;
-    double *snap_dev[STREAM_NB] = {};   // [HW*4]: params (HW*3) | dlog (HW)
-    double *snap_host[STREAM_NB] = {};  // pinned
-    hipEvent_t snap_ready[STREAM_NB] = {}, snap_done[STREAM_NB] = {};
-    // RCCL communicator of the tiled chain (d3d_comm_init)
-    ncclComm_t comm = nullptr;
-    int comm_rank = -1, comm_size = 0;
-    std::vector<uint8_t> h_mask;
-
-    bool have_taps = false, have_data = false, have_params = false, have_cfg = false;
-    bool err_valid = false;
-    double min_b[3] = {}, max_b[3] = {}, amp[3] = {};
-    double ra = 0;
-    uint64_t seed = 0;
-    int refresh_every = 1000;
-    uint32_t sweep_origin = 0;  // Philox sweep index of sweep s is s + sweep_origin (resumed runs)
-
-    int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry
-    int mh_defer = 1;             // deferred residual write-back (k_mh_defer)
-#ifdef D3D_EXPERIMENTS
-    unsigned long long *stampbuf = nullptr;  // D3D_MH_STAMP=1: [launch][workgroup][8]
-    size_t stamp_launches = 0, stamp_next = 0, stamp_stride = 0;
-#endif
-    bool ivar_is_uniform = false; // SLOT_IVAR holds one constant (k_mh_ws<.., true> skips reading it)
-    double ivar_uniform = 0.0;
-    bool uniform_fast_path = true;  // D3D_UNIFORM_IVAR=0 turns the variant off
-    double *gbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // update coefficients [slots][Dp]
-    // pending layers, oldest first: colour class and G buffer of each update that has
-    // not been written into SLOT_ERR yet (k_mh_ws applies up to mh_layers of them)
-    int lay_n = 0, lay_cy[3] = {-1, -1, -1}, lay_cx[3] = {-1, -1, -1}, lay_g[3] = {0, 0, 0};
-    int mh_layers = 2;            // pending layers in use by the first part (d3d_mh_layers)
-    bool mh_nt_ivar = false;      // 1/variance loads non-temporal: residual + 1/variance exceed the Infinity Cache (D3D_MH_NT_IVAR)
-    int mh_zigzag = 1;            // D3D_MH_ZIGZAG=0|1: odd colour ordinals walk windows / work lists backwards (MHArgs::rev)
-    int mh_layers_cfg = 2;        // D3D_MH_LAYERS=1|2|3; small cubes fall back to 1 unless it is set
-    bool mh_layers_forced = false;
-    // dataflow kernel (k_mh_flow): one launch per sweep
-    int mh_flow = 0;              // D3D_MH_FLOW=1: one launch per sweep (k_mh_flow; measured
-                                  // slower than one k_mh_ws launch per colour: DESIGN.md)
-    int flow_K = 0, flow_LY = 0, flow_LX = 0, flow_items = 0, flow_grid = 0;
-    int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
-    // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
-    // monotonic ticket counter, so that nothing needs clearing between launches
-    int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
-    int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
-                                   // measured 43.0 vs 42.0 us per colour: opt-in)
-    unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item
-    unsigned pair_epoch = 0, pair_tickets = 0;
-    std::vector<int> flow_first;   // first item of every active colour (+ total)
-    std::vector<int> flow_colour;  // colour class index of every active colour
-    int4 *flow_ent = nullptr;     // [items] {y, x, real, colour ordinal}
-    int4 *flow_col = nullptr;     // [K] {first ticket, cy, cx, -}
-    int *flow_lat = nullptr;      // [K][LY*LX]
-    unsigned *flow_state = nullptr;  // one block, zeroed per launch: ctl[4] | cnt[K] | done[items]
-    unsigned *flow_err = nullptr;    // sticky error word of k_mh_flow
-    size_t flow_state_bytes = 0, flow_cap_items = 0, flow_cap_K = 0;
-    int slots_x = 0, slots = 0;
-    int gy0 = 0, gx0 = 0, Wg = 0;    // tile origin / global width (RNG keys)
-    bool tiled = false;              // d3d_set_tile was called
-    int oy0 = 0, oy1 = 0, ox0 = 0, ox1 = 0;  // owned local rectangle
-    double *prev = nullptr;          // [HW*3] parameters before each spaxel's last update
-    double *recbuf = nullptr;        // [HW*8] staging of update records
-    int *idxbuf = nullptr;           // [HW] staging of spaxel lists
-    double *extbuf = nullptr;        // external-lines staging: [cap][6 + 2D] doubles
-    size_t ext_cap = 0;              // spaxels per d3d_mh_colour_lines call it can hold
-    bool fsf_sep = false;         // fsf == u v^T to rounding (k_spatial_sep); D3D_SPATIAL_SEP=0 disables
-    bool sep_fuse = true;         // LSF in the same pass (k_spatial_sep_lsf); D3D_SEP_FUSE=0 disables
-    double *sep_uv = nullptr;     // [fh + fw] on the device
-    bool fsf_symx = false;        // fsf[k][i] == fsf[k][fw-1-i] bit for bit
-    bool fsf_symy = false;        // fsf[k][i] == fsf[fh-1-k][i] bit for bit
-    double *fsf_quad = nullptr;   // [(fhh+1)^2] quadrant taps of an x/y-symmetric square FSF (k_conv_rows)
-    double *fsf_quad_sep = nullptr;  // the same table for an outer-product FSF: row 0 = v, row 1 = u
-    bool fsf_symt = false;        // ... and fsf[k][i] == fsf[i][k] bit for bit (radial FSFs)
-    bool lsf_dense_sym = false;   // dense LSF weights mirror-symmetric bit for bit
-    int conv_rows = 1;            // D3D_CONV_ROWS=0: never use the one-pass kernel k_conv_rows
-    double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
-    bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
-    bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
-    int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
-    int spectral_shfl = 0;        // D3D_SPECTRAL_SHFL=1: wavefront shuffles instead of the LDS window
-    int fuse_lsf = 0;             // D3D_FUSE_LSF=1: LSF in the march epilogue (correct; slower today: register spills)
-    int march_hy = 16;            // output rows per strip of the march kernel
-    int zmajor_hy = 32;           // output rows per strip of the z-major spatial kernel
-    int march_one = 0;            // D3D_MARCH_ONE=2|3: one-channel-per-lane variant, TX columns
-    int march_pf = 0;             // D3D_MARCH_PF=2|3: software-pipelined variant, TX columns
-    // 0: tile kernel; 1: march; 2: march + the mirror symmetries the FSF has (x, and y on
-    // top of x); 3: march + x symmetry only
-    int march_mode = 2;
-    int sp_nt = 256;              // spectral / spatial block size
-};
-
 namespace {
 
 using namespace d3d;
-
-d3d::SpectralArgs spectral_args(const d3d_ctx *c) {
-    d3d::SpectralArgs A;
-    A.D = c->D;
-    A.Dp = c->Dp;
-    A.HL = c->HL;
-    A.N = c->N;
-    A.ntaps = c->ntaps;
-    A.nspax = c->HW;
-    A.shift = c->lsf_shift;
-    A.weight = c->lsf_weight;
-    return A;
-}
-
-// block size for the group-per-spaxel kernels: at least HL threads.
-int pick_nt(int HL) {
-    if (HL <= 256) return 256;
-    if (HL <= 512) return 512;
-    return 1024;
-}
 
 int to_device_layout(d3d_ctx *c, const double *src_stage, double *dst) {
     dim3 grid((unsigned)((c->HW + 31) / 32), (unsigned)((c->Dp + 31) / 32));
@@ -284,811 +92,12 @@ int download_cube(d3d_ctx *c, const double *src, double *host) {
     return 0;
 }
 
-template <int NT>
-int launch_lines_nt(d3d_ctx *c, double *out, int convolved, const double *params) {
-    d3d::SpectralArgs A = spectral_args(c);
-    const int G = NT / c->HL;
-    const unsigned grid = (unsigned)((c->HW + G - 1) / G);
-    const size_t lds = (size_t)G * c->N * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_lines<NT>), dim3(grid), dim3(NT), lds, c->stream, A,
-                       params, c->mask, out, convolved);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// params: (H,W,3) map on the device (NULL: the chain state c->params)
-int launch_lines(d3d_ctx *c, double *out, int convolved, const double *params = nullptr) {
-    if (!params) params = c->params;
-    switch (pick_nt(c->HL)) {
-        case 256: return launch_lines_nt<256>(c, out, convolved, params);
-        case 512: return launch_lines_nt<512>(c, out, convolved, params);
-        default: return launch_lines_nt<1024>(c, out, convolved, params);
-    }
-}
-
-template <int NT>
-int launch_spectral_nt(d3d_ctx *c, const double *in, double *out) {
-    d3d::SpectralArgs A = spectral_args(c);
-    const int G = NT / c->HL;
-    const unsigned grid = (unsigned)((c->HW + G - 1) / G);
-    const size_t lds = (size_t)G * c->N * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral<NT>), dim3(grid), dim3(NT), lds, c->stream,
-                       A, in, out);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int launch_spectral(d3d_ctx *c, const double *in, double *out) {
-    if (c->lsf_fusable && c->spectral_dense) {
-        // dense +-LSF_RL taps, spectrum within one wavefront: streaming form
-        const int NT = 256, G = NT / c->HL;
-        const unsigned grid = (unsigned)((c->HW + G - 1) / G);
-        if (c->spectral_shfl && c->HL == 64) {  // neighbours by wavefront shuffles, no LDS
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral_shfl<256>), dim3(grid), dim3(NT), 0,
-                               c->stream, c->Dp, c->HW, (const double *)c->lsf_dense, in, out);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-        const size_t lds = (size_t)G * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spectral_dense<256>), dim3(grid), dim3(NT), lds,
-                           c->stream, c->Dp, c->HL, c->HW, (const double *)c->lsf_dense, in, out);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    switch (pick_nt(c->HL)) {
-        case 256: return launch_spectral_nt<256>(c, in, out);
-        case 512: return launch_spectral_nt<512>(c, in, out);
-        default: return launch_spectral_nt<1024>(c, in, out);
-    }
-}
-
-template <int NT, int FW>
-int launch_spatial_fw(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    constexpr int TX = 8;
-    const int S = NT / c->HL;
-    const long strips = (long)c->H * ((c->W + TX - 1) / TX);
-    const unsigned grid = (unsigned)((strips + S - 1) / S);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial<NT, FW, TX>), dim3(grid), dim3(NT), 0,
-                       c->stream, A, in, out);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NT, int FS, int TX, bool SYMX, bool UNI, bool FUSE, bool SYMY>
-int launch_march(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    const int S = NT / c->HL;
-    const int HY = c->march_hy;
-    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
-    const unsigned grid = (unsigned)((items + S - 1) / S);
-    const size_t lds =
-        FUSE ? (size_t)S * TX * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double) : 0;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, SYMX, UNI, FUSE, SYMY>),
-                       dim3(grid), dim3(NT), lds, c->stream, A, in, out, HY);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-#ifdef D3D_EXPERIMENTS
-// Diagnostic build (D3D_STAMP=1): the xy-symmetric march kernel with in-kernel
-// s_memtime stamps; prints the per-phase cycle shares of a march step to stderr.
-template <int NT, int FS, int TX>
-int launch_march_stamped(d3d_ctx *c, d3d::SpatialArgs A, const double *in, double *out) {
-    const int S = NT / c->HL;
-    const int HY = c->march_hy;
-    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
-    const unsigned grid = (unsigned)((items + S - 1) / S);
-    const size_t nw = (size_t)grid * (NT / 64);
-    unsigned long long *dbg = nullptr;
-    HIP_TRY(hipMalloc(&dbg, nw * 8 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemsetAsync(dbg, 0, nw * 8 * sizeof(unsigned long long), c->stream));
-    A.dbg = dbg;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march<NT, FS, TX, true, true, false, true, true>),
-                       dim3(grid), dim3(NT), 0, c->stream, A, in, out, HY);
-    HIP_TRY(hipGetLastError());
-    std::vector<unsigned long long> h(nw * 8);
-    HIP_TRY(hipMemcpyAsync(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                           c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(dbg);
-    double sum[5] = {0, 0, 0, 0, 0}, steps = 0;
-    unsigned long long tmin = ~0ULL, tmax = 0;
-    size_t live = 0;
-    for (size_t w = 0; w < nw; ++w) {
-        if (!h[w * 8 + 5]) continue;
-        ++live;
-        for (int k = 0; k < 5; ++k) sum[k] += (double)h[w * 8 + k];
-        steps += (double)h[w * 8 + 5];
-        if (h[w * 8 + 6] < tmin) tmin = h[w * 8 + 6];
-        if (h[w * 8 + 7] > tmax) tmax = h[w * 8 + 7];
-    }
-    fprintf(stderr,
-            "[d3d stamp] waves %zu steps/wave %.1f | cycles per step: issue %.0f wait %.0f math %.0f "
-            "tail %.0f | wave lifetime %.0f cyc | kernel span %.0f cyc\n",
-            live, steps / live, sum[0] / steps, sum[1] / steps, sum[2] / steps, sum[3] / steps,
-            sum[4] / live, (double)(tmax - tmin));
-    return 0;
-}
-
-#endif  // D3D_EXPERIMENTS
-
-// One pass for LSF x outer-product FSF (A.lsf_dense set; a strip within a wavefront).
-template <int NT, int FS>
-int launch_sep_lsf(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    constexpr int TX = (FS >= 9 ? 3 : 4);
-    const int S = NT / c->HL;
-    const int HY = c->march_hy;
-    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
-    const unsigned grid = (unsigned)((items + S - 1) / S);
-    const size_t lds = (size_t)S * TX * (c->Dp + 2 * d3d::LSF_RL) * sizeof(double);
-    if ((c->HL % 64) == 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep_lsf<NT, FS, TX, true>), dim3(grid),
-                           dim3(NT), lds, c->stream, A, in, out, HY);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep_lsf<NT, FS, TX, false>), dim3(grid),
-                           dim3(NT), lds, c->stream, A, in, out, HY);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NT, int FS>
-int launch_sep(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    if (A.lsf_dense) return launch_sep_lsf<NT, FS>(c, A, in, out);
-    constexpr int TX = (FS >= 9 ? 3 : 4);
-    const int S = NT / c->HL;
-    const int HY = c->march_hy;
-    const long items = (long)((c->W + TX - 1) / TX) * ((c->H + HY - 1) / HY);
-    const unsigned grid = (unsigned)((items + S - 1) / S);
-    if ((c->HL % 64) == 0)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep<NT, FS, TX, true>), dim3(grid),
-                           dim3(NT), 0, c->stream, A, in, out, HY);
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_sep<NT, FS, TX, false>), dim3(grid),
-                           dim3(NT), 0, c->stream, A, in, out, HY);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NT, int FS, bool FUSE>
-int launch_march_fs(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out) {
-    if (A.sep_uv && (!FUSE || c->sep_fuse)) return launch_sep<NT, FS>(c, A, in, out);
-    constexpr int TX = (FS >= 9 ? 3 : 4);
-    const bool uni = (c->HL % 64) == 0;  // a wavefront never straddles two strips
-    const bool symx = c->march_mode >= 2 && c->fsf_symx;
-    const bool symxy = symx && c->fsf_symy && c->march_mode != 3;  // mode 3: x symmetry only
-#ifdef D3D_EXPERIMENTS
-    if (symxy && !FUSE && c->march_one > 0 && c->Dp % 64 == 0 && NT % c->Dp == 0) {
-        // one channel per lane: 3 (TX = 3) or 4 (TX = 2) wavefronts per SIMD
-        const int HY = c->march_hy;
-        const int S = NT / c->Dp;
-        if (c->march_one == 3) {
-            const long items = (long)((c->W + 2) / 3) * ((c->H + HY - 1) / HY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march1<NT, FS, 3, 3>),
-                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
-                               out, HY);
-        } else {
-            const long items = (long)((c->W + 1) / 2) * ((c->H + HY - 1) / HY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march1<NT, FS, 2, 4>),
-                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
-                               out, HY);
-        }
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-    if (uni && symxy && !FUSE && c->march_pf > 0) {
-        // software-pipelined variant (next-row loads interleaved with the FMAs)
-        const int HY = c->march_hy;
-        const int S = NT / c->HL;
-        if (c->march_pf == 3) {
-            const long items = (long)((c->W + 2) / 3) * ((c->H + HY - 1) / HY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march_pf<NT, FS, 3>),
-                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
-                               out, HY);
-        } else {
-            const long items = (long)((c->W + 1) / 2) * ((c->H + HY - 1) / HY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_march_pf<NT, FS, 2>),
-                               dim3((unsigned)((items + S - 1) / S)), dim3(NT), 0, c->stream, A, in,
-                               out, HY);
-        }
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
-#endif
-    if (uni) {
-#ifdef D3D_EXPERIMENTS
-        if constexpr (FS == 11 && !FUSE && NT == 256) {
-            if (symxy && getenv("D3D_STAMP")) return launch_march_stamped<NT, FS, TX>(c, A, in, out);
-        }
-#endif
-        if (symxy) return launch_march<NT, FS, TX, true, true, FUSE, true>(c, A, in, out);
-        if (symx) return launch_march<NT, FS, TX, true, true, FUSE, false>(c, A, in, out);
-        return launch_march<NT, FS, TX, false, true, FUSE, false>(c, A, in, out);
-    }
-    if (symxy) return launch_march<NT, FS, TX, true, false, FUSE, true>(c, A, in, out);
-    if (symx) return launch_march<NT, FS, TX, true, false, FUSE, false>(c, A, in, out);
-    return launch_march<NT, FS, TX, false, false, FUSE, false>(c, A, in, out);
-}
-
-template <int NT, bool FUSE>
-int launch_march_any(d3d_ctx *c, const d3d::SpatialArgs &A, const double *in, double *out,
-                     bool *done) {
-    *done = true;
-    switch (c->fw) {
-        case 3: return launch_march_fs<NT, 3, FUSE>(c, A, in, out);
-        case 5: return launch_march_fs<NT, 5, FUSE>(c, A, in, out);
-        case 7: return launch_march_fs<NT, 7, FUSE>(c, A, in, out);
-        case 9: return launch_march_fs<NT, 9, FUSE>(c, A, in, out);
-        case 11: return launch_march_fs<NT, 11, FUSE>(c, A, in, out);
-        case 13: return launch_march_fs<NT, 13, FUSE>(c, A, in, out);
-        case 15: return launch_march_fs<NT, 15, FUSE>(c, A, in, out);
-        default: break;
-    }
-    *done = false;
-    return 0;
-}
-
-template <int NT>
-int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *data,
-                      bool fuse_lsf) {
-    d3d::SpatialArgs A;
-    A.Dp = c->Dp;
-    A.HL = c->HL;
-    A.H = c->H;
-    A.W = c->W;
-    A.fh = c->fh;
-    A.fw = c->fw;
-    A.fsf = c->fsf;
-    A.data = data;
-    A.lsf_dense = nullptr;
-    A.sep_uv = (c->fsf_sep && (!fuse_lsf || c->sep_fuse)) ? c->sep_uv : nullptr;
-    A.xcd_remap = getenv("D3D_XCD_REMAP") ? atoi(getenv("D3D_XCD_REMAP")) : 1;
-    A.alt_dir = getenv("D3D_ALT_DIR") ? atoi(getenv("D3D_ALT_DIR")) : 1;
-    A.dbg = nullptr;
-    A.stagger = getenv("D3D_STAGGER") ? atoi(getenv("D3D_STAGGER")) : 0;
-    // (the march kernels are built for 256-thread groups only: D <= 512; deeper
-    // cubes use the tile kernel below)
-    if constexpr (NT == 256)
-    if (c->march_mode > 0 && c->fh == c->fw) {
-        bool done = false;
-        int rc;
-        if (fuse_lsf && A.sep_uv && c->sep_fuse) {  // LSF x outer-product FSF in one pass
-            A.lsf_dense = c->lsf_dense;
-            rc = launch_march_any<NT, false>(c, A, in, out, &done);
-            if (done) return rc;
-            A.lsf_dense = nullptr;
-        }
-#ifdef D3D_EXPERIMENTS
-        if (fuse_lsf) {
-            A.lsf_dense = c->lsf_dense;
-            rc = launch_march_any<NT, true>(c, A, in, out, &done);
-        } else
-#endif
-        {
-            rc = launch_march_any<NT, false>(c, A, in, out, &done);
-        }
-        if (done) return rc;
-        A.lsf_dense = nullptr;
-    }
-    if (fuse_lsf) return fail(D3D_ERR_STATE, "internal: fused LSF requested without march kernel");
-    switch (c->fw) {
-        case 1: return launch_spatial_fw<NT, 1>(c, A, in, out);
-        case 3: return launch_spatial_fw<NT, 3>(c, A, in, out);
-        case 5: return launch_spatial_fw<NT, 5>(c, A, in, out);
-        case 7: return launch_spatial_fw<NT, 7>(c, A, in, out);
-        case 9: return launch_spatial_fw<NT, 9>(c, A, in, out);
-        case 11: return launch_spatial_fw<NT, 11>(c, A, in, out);
-        case 13: return launch_spatial_fw<NT, 13>(c, A, in, out);
-        case 15: return launch_spatial_fw<NT, 15>(c, A, in, out);
-        default: break;
-    }
-    const int S = NT / c->HL;
-    const unsigned grid = (unsigned)((c->HW + S - 1) / S);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_generic<NT>), dim3(grid), dim3(NT), 0,
-                       c->stream, A, in, out);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// ---- one-pass kernel k_conv_rows (d3d_conv.h) ---------------------------------------
-// Usable for a 128-channel spectrum (one wavefront per column) and a square FSF with
-// both mirror symmetries; with_lsf additionally needs the dense power-of-two LSF form.
-bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
-    if (!c->conv_rows || c->Dp != d3d::CONV_DP) return false;
-    if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
-    if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D)) return false;
-    switch (c->fw) {
-        case 3: case 5: case 7: case 9: case 11: case 13: return true;
-        default: return false;
-    }
-}
-
-template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM>
-int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
-    constexpr int NW = 15;
-    d3d::ConvRowsArgs A;
-    A.H = c->H;
-    A.W = c->W;
-    A.ngx = (c->W + NW - 1) / NW;
-    // one workgroup per CU (1024 threads, ~93 KB of LDS): as many row strips as fill the
-    // chip in ONE round
-    const int cus = c->flow_grid > 0 ? c->flow_grid / 4 : 256;
-    int ngy = std::max(1, cus / A.ngx);
-    ngy = std::min(ngy, c->H);
-    A.HY = (c->H + ngy - 1) / ngy;
-    if (const char *e = getenv("D3D_CONV_HY")) {
-        const int v = atoi(e);
-        if (v >= 1) A.HY = v;
-    }
-    A.ngy = (c->H + A.HY - 1) / A.HY;
-    A.xcd_remap = 1;
-    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM>;
-    constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW>();
-    // > 64 KB of dynamic LDS has to be allowed per function AND per device: set on every
-    // launch (a host-side call of a few microseconds; this kernel is not in the MH loop)
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
-                       in, out, (const double *)(TSYM == 2 ? c->fsf_quad_sep : c->fsf_quad),
-                       (const double *)c->lsf_dense, data);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int FS, int TSYM>
-int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    const bool sym = c->lsf_dense_sym;
-    if (lsf) {
-        if (data) return sym ? launch_conv_rows_t<FS, true, true, true, TSYM>(c, in, out, data)
-                             : launch_conv_rows_t<FS, true, false, true, TSYM>(c, in, out, data);
-        return sym ? launch_conv_rows_t<FS, true, true, false, TSYM>(c, in, out, data)
-                   : launch_conv_rows_t<FS, true, false, false, TSYM>(c, in, out, data);
-    }
-    if (data) return launch_conv_rows_t<FS, false, false, true, TSYM>(c, in, out, data);
-    return launch_conv_rows_t<FS, false, false, false, TSYM>(c, in, out, data);
-}
-
-template <int FS>
-int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2>(c, in, out, data, lsf);
-    if (c->fsf_symt) return launch_conv_rows_ts<FS, 1>(c, in, out, data, lsf);
-    return launch_conv_rows_ts<FS, 0>(c, in, out, data, lsf);
-}
-
-int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    switch (c->fw) {
-        case 3: return launch_conv_rows_fs<3>(c, in, out, data, lsf);
-        case 5: return launch_conv_rows_fs<5>(c, in, out, data, lsf);
-        case 7: return launch_conv_rows_fs<7>(c, in, out, data, lsf);
-        case 9: return launch_conv_rows_fs<9>(c, in, out, data, lsf);
-        case 11: return launch_conv_rows_fs<11>(c, in, out, data, lsf);
-        default: return launch_conv_rows_fs<13>(c, in, out, data, lsf);
-    }
-}
-
-// True when the spatial pass can apply the LSF itself (fused epilogue).
-bool can_fuse_lsf(const d3d_ctx *c) {
-    // (an outer-product FSF honours D3D_SEP_FUSE=0: LSF in its own pass, for A/B tests)
-    if (conv_rows_usable(c, true) && !(c->fsf_sep && c->march_mode > 0 && !c->sep_fuse)) return true;
-    if (!c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
-    const bool sep = c->fsf_sep && c->sep_fuse;  // k_spatial_sep_lsf
-#ifndef D3D_EXPERIMENTS
-    // the fused epilogue of the 2-D march kernel is an experiment (register spills:
-    // slower than the streaming LSF pass)
-    if (!sep) return false;
-#else
-    if (!sep && !c->fuse_lsf) return false;
-#endif
-    switch (c->fw) {
-        case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;
-        default: return false;
-    }
-}
-
-// out = FSF (*) in, or data - FSF (*) in when data != NULL.  in != out.
-// fuse_lsf: also apply the LSF along z (only when can_fuse_lsf()).
-int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
-                   bool fuse_lsf = false) {
-    if (conv_rows_usable(c, fuse_lsf)) return launch_conv_rows(c, in, out, data, fuse_lsf);
-    int nt = pick_nt(c->HL);
-    if (const char *e = getenv("D3D_SPATIAL_NT")) {
-        const int v = atoi(e);
-        if ((v == 256 || v == 512 || v == 1024) && v >= nt) nt = v;
-    }
-    switch (nt) {
-        case 256: return launch_spatial_nt<256>(c, in, out, data, fuse_lsf);
-        case 512: return launch_spatial_nt<512>(c, in, out, data, fuse_lsf);
-        default: return launch_spatial_nt<1024>(c, in, out, data, fuse_lsf);
-    }
-}
-
-void pend_clear(d3d_ctx *c) {
-    c->lay_n = 0;
-    c->pend_part = -1;
-}
-
-// a G buffer that holds no pending layer
-int pend_free_buf(const d3d_ctx *c) {
-    for (int b = 0; b < 4; ++b) {
-        bool used = false;
-        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
-        if (!used) return b;
-    }
-    return 0;  // unreachable: at most 3 layers
-}
-
-void pend_push(d3d_ctx *c, int cy, int cx, int g) {
-    c->lay_cy[c->lay_n] = cy;
-    c->lay_cx[c->lay_n] = cx;
-    c->lay_g[c->lay_n] = g;
-    ++c->lay_n;
-}
-
-// params -> SLOT_TMP0 (LSF lines) -> dst (sim, or residual when resid)
-int forward_into(d3d_ctx *c, double *dst, bool resid) {
-    if (resid) pend_clear(c);  // a fresh residual supersedes pending updates
-    const double *data = resid ? c->slot[D3D_SLOT_DATA] : nullptr;
-    // FSF and LSF commute: where the spatial kernel can apply the LSF in its epilogue the
-    // lines are built raw (exp only) and the LSF costs no pass of its own
-    if (c->ntaps > 0 && can_fuse_lsf(c)) {
-        int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 0);
-        if (rc) return rc;
-        return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, data, true);
-    }
-    int rc = launch_lines(c, c->slot[D3D_SLOT_TMP0], 1);
-    if (rc) return rc;
-    return launch_spatial(c, c->slot[D3D_SLOT_TMP0], dst, data);
-}
-
-void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
-    P.D = c->D;
-    P.Dp = c->Dp;
-    P.HL = c->HL;
-    P.H = c->H;
-    P.W = c->W;
-    P.fh = c->fh;
-    P.fw = c->fw;
-    P.N = c->N;
-    P.ntaps = c->ntaps;
-    P.npos = c->fh * c->fw;
-    P.err = c->slot[D3D_SLOT_ERR];
-    P.ivar = c->slot[D3D_SLOT_IVAR];
-    P.ivar_uniform = c->ivar_uniform;
-    P.params = c->params;
-    P.prev = c->prev;
-    P.fsf = c->fsf;
-    P.shift = c->lsf_shift;
-    P.weight = c->lsf_weight;
-    P.dlog = c->dlog;
-    P.accepted = c->accepted;
-    P.spx = c->spx;
-    P.rev = 0;
-    for (int k = 0; k < 3; ++k) {
-        P.min_b[k] = c->min_b[k];
-        P.max_b[k] = c->max_b[k];
-        P.amp[k] = c->amp[k];
-    }
-    P.ra = c->ra;
-    P.seed = c->seed;
-    P.gy0 = c->gy0;
-    P.gx0 = c->gx0;
-    P.Wg = c->Wg;
-    // the domain of the part whose layers are pending (the whole cube when none are)
-    if (c->pend_part >= 0 && c->pend_part < (int)c->parts.size()) {
-        const d3d_ctx::Part &pt = c->parts[c->pend_part];
-        P.dy0 = pt.dy0;
-        P.dy1 = pt.dy1;
-        P.dx0 = pt.dx0;
-        P.dx1 = pt.dx1;
-    } else {
-        P.dy0 = 0;
-        P.dy1 = c->H;
-        P.dx0 = 0;
-        P.dx1 = c->W;
-    }
-    P.mask = c->mask;
-    P.n_lay = c->lay_n;
-    P.write_back = 1;
-    for (int j = 0; j < 3; ++j) {
-        const bool live = j < c->lay_n;
-        P.lay_cy[j] = live ? c->lay_cy[j] : -1;
-        P.lay_cx[j] = live ? c->lay_cx[j] : -1;
-        P.lay_G[j] = c->gbuf[live ? c->lay_g[j] : 0];
-    }
-    P.Gcur = c->gbuf[pend_free_buf(c)];
-    // the kernels that keep one pending layer (k_mh_defer, k_mh_flow) see the newest
-    const int last = c->lay_n - 1;
-    P.Gprev = c->gbuf[last >= 0 ? c->lay_g[last] : 0];
-    P.prev_cy = last >= 0 ? c->lay_cy[last] : -1;
-    P.prev_cx = last >= 0 ? c->lay_cx[last] : -1;
-    P.slots_x = c->slots_x;
-    P.ext_idx = nullptr;
-    P.ext_in = nullptr;
-    P.ext_lines = nullptr;
-    P.ext_out = nullptr;
-    P.ext_gibbs = 1;
-    P.probe = 0;
-    P.probe_sp = 0;
-    P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
-    P.probe_out = c->scal;
-#ifdef D3D_EXPERIMENTS
-    P.stamp = nullptr;
-#endif
-}
-
-template <int NT, int MAXIT>
-int launch_mh_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh<NT, MAXIT>), dim3(grid), dim3(NT), lds, c->stream,
-                       P, sweep);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NT>
-int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    switch (c->mh_maxit) {
-        case 4: return launch_mh_t<NT, 4>(c, P, grid, sweep);
-        case 8: return launch_mh_t<NT, 8>(c, P, grid, sweep);
-        case 16: return launch_mh_t<NT, 16>(c, P, grid, sweep);
-        case 32: return launch_mh_t<NT, 32>(c, P, grid, sweep);
-        default: return launch_mh_t<NT, 0>(c, P, grid, sweep);
-    }
-}
-
-int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    switch (c->mh_nt) {
-        case 128: return launch_mh_nt<128>(c, P, grid, sweep);
-        case 256: return launch_mh_nt<256>(c, P, grid, sweep);
-        case 512: return launch_mh_nt<512>(c, P, grid, sweep);
-        default: return launch_mh_nt<1024>(c, P, grid, sweep);
-    }
-}
-
-template <int NT>
-int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_defer<NT>), dim3(grid), dim3(NT), lds, c->stream,
-                       P, sweep);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <bool UV, int U, int M, int K, bool NTV = false, int NS = 256>
-int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
-    // (the number of pending layers as a template constant: see k_mh_ws)
-    switch (P.n_lay <= M ? P.n_lay : -1) {
-        case 0:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0, NTV>), dim3(grid),
-                               dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
-        case 1:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1, NTV>), dim3(grid),
-                               dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
-        case 2:
-            if constexpr (M >= 2)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2, NTV>), dim3(grid),
-                                   dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
-        case 3:
-            if constexpr (M >= 3)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3, NTV>), dim3(grid),
-                                   dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
-        default:
-            return fail(D3D_ERR_STATE, "internal: %d pending layers for a %d-layer kernel", P.n_lay, M);
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-// A launch that does not fill the chip (fewer workgroups than 2 per CU) is
-// latency-bound: four window positions in flight per wavefront instead of one.
-// The kernels for several pending layers need more LDS; with one layer
-// configured the lean variant runs.  The pending G rows of a layer (4*Dp values)
-// are staged in 2 registers per thread up to Dp = 160, in 4 beyond.
-template <bool UV>
-int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    // (the uniform-variance variant also gains from the deeper queue at full size:
-    // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
-    const bool small = UV || grid < (unsigned)c->flow_grid / 2;
-    // (with several layers most launches only read: two positions in flight pay at
-    // full size, 43.3 -> 42.6 us per colour; chosen per kind of launch instead -- four for
-    // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
-    // against 40.8 with two for both.  Round 2, for launches that do not fill the
-    // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
-    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); fifteen
-    // streaming wavefronts per window: see the 960-thread form below)
-    // (1/variance with the non-temporal hint when the context's working set exceeds the
-    // Infinity Cache: mh_load_ivar; only the chip-filling launches have the variant)
-    if constexpr (!UV) {
-        if (c->mh_nt_ivar && !small) {
-            if (c->mh_layers >= 3) return launch_mh_ws_um<UV, 2, 3, 2, true>(c, P, grid, sweep);
-            if (c->mh_layers == 2) {
-                if (c->Dp > 160) return launch_mh_ws_um<UV, 2, 2, 4, true>(c, P, grid, sweep);
-                return launch_mh_ws_um<UV, 2, 2, 2, true>(c, P, grid, sweep);
-            }
-            return launch_mh_ws_um<UV, 1, 1, 4, true>(c, P, grid, sweep);
-        }
-    }
-    if (c->mh_layers >= 3) {  // Dp <= 160
-        if (small) return launch_mh_ws_um<UV, 4, 3, 2>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 2, 3, 2>(c, P, grid, sweep);
-    }
-    if (c->mh_layers == 2) {
-        if (c->Dp > 160) {
-            if (small) return launch_mh_ws_um<UV, 4, 2, 4>(c, P, grid, sweep);
-            return launch_mh_ws_um<UV, 2, 2, 4>(c, P, grid, sweep);
-        }
-        if (small) return launch_mh_ws_um<UV, 4, 2, 2>(c, P, grid, sweep);
-        return launch_mh_ws_um<UV, 2, 2, 2>(c, P, grid, sweep);
-    }
-    // The small launches of a PARTITIONED context (tiles, d3d_set_parts) at 128 channels: a
-    // launch of at most one workgroup per CU is bound by how fast ONE workgroup gets through
-    // its window (121 positions through four wavefronts, ~1 us per round trip), so fifteen
-    // streaming wavefronts instead of four (k_mh_ws<960>, ONE position in flight per
-    // wavefront: 3.52 ms against 3.61 with two and 3.77 with four): an 8x1 rank of
-    // 300x300x128 4.18 -> 3.52 ms per sweep.  (What then bounds such a launch, by the phase
-    // stamps: setup 2.3 us, the prepare wavefront's proposal -> line -> LSF chain 6.4, the
-    // decision tail 4.5, the kernel boundary 2.4; a second prepare wavefront for the
-    // current line gained 1.5 %: not kept.)  Another grouping of the window sums than the 256-thread form
-    // (results agree to rounding, not bit for bit), hence only where nothing is compared bit for
-    // bit with another scheme: a given part always takes the same form, so a tiled chain and
-    // the single context given the same parts still agree to the last bit.  Shallow cubes lose
-    // (32 channels: 9.9 -> 12.2 us per launch).  D3D_MH_WIDE=0: off.
-    if (small && c->mh_wide && (c->tiled || !c->part_rects.empty()) && c->Dp == 128 &&
-        grid <= (unsigned)c->flow_grid / 4)
-        return launch_mh_ws_um<UV, 1, 1, 1, false, 960>(c, P, grid, sweep);
-    if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
-    return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
-}
-
-// One sweep in one launch (k_mh_flow).  P carries the pending colour of the
-// previous sweep; afterwards the last active colour of this one is pending.
-template <bool UV>
-int launch_mh_flow_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHFlow &F, uint32_t sweep) {
-    constexpr int NS = 256;
-    size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
-    lds += 16;  // the ticket
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_flow<NS, UV>), dim3((unsigned)c->flow_items),
-                       dim3(NS + 64), lds, c->stream, P, F, sweep);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
-    HIP_TRY(hipMemsetAsync(c->flow_state, 0, c->flow_state_bytes, c->stream));
-    d3d::MHArgs P;
-    fill_mh_args(c, P);
-    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
-    d3d::MHFlow F;
-    F.ent = c->flow_ent;
-    F.col = c->flow_col;
-    F.lat = c->flow_lat;
-    F.ctl = c->flow_state;
-    F.cnt = c->flow_state + 4;
-    F.done = c->flow_state + 4 + c->flow_cap_K;
-    F.err = c->flow_err;
-    for (int b = 0; b < 3; ++b) F.gbuf[b] = c->gbuf[b];
-    F.K = c->flow_K;
-    F.LY = c->flow_LY;
-    F.LX = c->flow_LX;
-    F.pb = c->lay_n ? c->lay_g[c->lay_n - 1] : 0;  // (one layer at most: launch_mh_flow's caller)
-    F.items = c->flow_items;
-    F.epoch = 1;
-    const int rc = (c->ivar_is_uniform && c->uniform_fast_path)
-                       ? launch_mh_flow_t<true>(c, P, F, sweep)
-                       : launch_mh_flow_t<false>(c, P, F, sweep);
-    if (rc) return rc;
-    pend_clear(c);
-    pend_push(c, c->flow_last_cy, c->flow_last_cx, (F.pb + c->flow_K) % 3);
-    return 0;
-}
-
-// Colours ka (N: one layer pending, nothing written) and ka+1 (W) of the active-colour
-// list in ONE launch (k_mh_pair).  P carries the one pending layer.
-template <bool UV, int U, int K>
-int launch_mh_pair_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHPair &F, uint32_t sweep) {
-    constexpr int NS = 256;
-    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, 2) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_pair<NS, UV, U, K>), dim3((unsigned)(F.n_a + F.n_b)),
-                       dim3(NS + 64), lds, c->stream, P, F, sweep);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
-    d3d::MHArgs P;
-    fill_mh_args(c, P);
-    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
-    d3d::MHPair F;
-    F.ent = c->flow_ent;
-    F.lat = c->flow_lat;
-    F.ctl = c->pair_state;
-    F.done = c->pair_state + 4;
-    F.err = c->flow_err;
-    F.first_a = c->flow_first[ka];
-    F.n_a = c->flow_first[ka + 1] - c->flow_first[ka];
-    F.first_b = c->flow_first[ka + 1];
-    F.n_b = c->flow_first[ka + 2] - c->flow_first[ka + 1];
-    F.ka = ka;
-    F.a_cy = c->flow_colour[ka] / c->fw;
-    F.a_cx = c->flow_colour[ka] % c->fw;
-    F.LY = c->flow_LY;
-    F.LX = c->flow_LX;
-    F.ticket_base = c->pair_tickets;
-    F.epoch = ++c->pair_epoch;
-    const int ga = pend_free_buf(c);
-    int gb = 0;
-    for (int b = 0; b < 4; ++b) {
-        bool used = b == ga;
-        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
-        if (!used) gb = b;
-    }
-    F.G_a = c->gbuf[ga];
-    F.G_b = c->gbuf[gb];
-    c->pair_tickets += (unsigned)(F.n_a + F.n_b);
-    const bool uv = c->ivar_is_uniform && c->uniform_fast_path;
-    int rc;
-    if (c->Dp > 160)
-        rc = uv ? launch_mh_pair_t<true, 4, 4>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 4>(c, P, F, sweep);
-    else
-        rc = uv ? launch_mh_pair_t<true, 4, 2>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 2>(c, P, F, sweep);
-    if (rc) return rc;
-    // afterwards colour B's updates are the only pending layer (local residues == colour
-    // indices: an unpartitioned, untiled context)
-    c->lay_n = 0;
-    pend_push(c, c->flow_colour[ka + 1] / c->fw, c->flow_colour[ka + 1] % c->fw, gb);
-    c->pend_part = 0;
-    return 0;
-}
-
-int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
-    // tail, so D <= 256) + one prepare wavefront
-    if (c->mh_defer == 1 && c->Dp <= 256) {
-        if (c->ivar_is_uniform && c->uniform_fast_path) return launch_mh_ws<true>(c, P, grid, sweep);
-        return launch_mh_ws<false>(c, P, grid, sweep);
-    }
-    switch (c->mh_nt) {
-        case 128: return launch_mh_defer_nt<128>(c, P, grid, sweep);
-        case 256: return launch_mh_defer_nt<256>(c, P, grid, sweep);
-        case 512: return launch_mh_defer_nt<512>(c, P, grid, sweep);
-        default: return launch_mh_defer_nt<1024>(c, P, grid, sweep);
-    }
-}
-
-// Write the pending (deferred) residual updates into SLOT_ERR.
-int flush_pending(d3d_ctx *c) {
-    if (c->lay_n == 0) return 0;
-    d3d::MHArgs P;
-    fill_mh_args(c, P);
-    const int NT = 256;
-    const int S = NT / c->HL > 0 ? NT / c->HL : 1;
-    const long cells = (long)(P.dy1 - P.dy0) * (P.dx1 - P.dx0);  // of the pending part's domain
-    if (cells > 0) {
-        if (c->HL <= 256) {
-            const unsigned grid = (unsigned)((cells + S - 1) / S);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
-                               c->stream, P);
-        } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)cells),
-                               dim3(1024), 0, c->stream, P);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    pend_clear(c);
-    return 0;
-}
-
 // Choose the MH workgroup: NT threads, window kept in MAXIT double2 registers
 // per thread (0 = window re-read from memory in pass 2).
 void pick_mh_geometry(d3d_ctx *c) {
     const int npos = c->fh * c->fw;
     int need = c->N > c->Dp ? c->N : c->Dp;
-    int nt_env = 0, mi_env = -1;
-    if (const char *e = getenv("D3D_MH_NT")) nt_env = atoi(e);
-    if (const char *e = getenv("D3D_MH_MAXIT")) mi_env = atoi(e);
+    const int nt_env = c->mh_nt_opt, mi_env = c->mh_maxit_opt;
     // Measured on MI355X (300x300x128, 11x11): small workgroups that re-read
     // the err window in pass 2 (MAXIT = 0) beat register-resident windows --
     // 6 workgroups per CU overlap each other's load / reduce / store phases.
@@ -1108,26 +117,20 @@ void pick_mh_geometry(d3d_ctx *c) {
         maxit = mi_env;
     c->mh_nt = nt;
     c->mh_maxit = maxit;
-    // 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain
-    if (const char *e = getenv("D3D_MH_DEFER")) c->mh_defer = atoi(e);
-    if (const char *e = getenv("D3D_UNIFORM_IVAR")) c->uniform_fast_path = atoi(e) != 0;
-    if (const char *e = getenv("D3D_MH_FLOW")) c->mh_flow = atoi(e);
-    if (const char *e = getenv("D3D_MH_PAIR")) c->mh_pair = atoi(e);
-    if (const char *e = getenv("D3D_MH_WIDE")) c->mh_wide = atoi(e);
-    if (const char *e = getenv("D3D_MH_ZIGZAG")) c->mh_zigzag = atoi(e) != 0;
+    // (mh_defer -- 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain)
     // measured crossover on MI355X (256 MiB Infinity Cache): 276 / 323 MB +1 %, 369 MB +6 %,
     // 230 MB -7 % (tools/mh_sizes.py)
-    // (the write-through residual stores of that variant address SLOT_ERR as a raw buffer: < 2 GiB)
-    c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6 &&
-                    8.0 * (double)c->Dp * (double)c->H * (double)c->W < 2147483648.0;
-    if (const char *e = getenv("D3D_MH_NT_IVAR")) c->mh_nt_ivar = atoi(e) != 0;
+    // The write-through residual stores of that variant address SLOT_ERR as a raw buffer
+    // with 32-bit byte offsets: never beyond 2 GiB, whatever the option says.
+    const bool fits_raw = 8.0 * (double)c->Dp * (double)c->H * (double)c->W < 2147483648.0;
+    c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6;
+    if (c->mh_nt_ivar_opt >= 0) c->mh_nt_ivar = c->mh_nt_ivar_opt != 0;
+    c->mh_nt_ivar = c->mh_nt_ivar && fits_raw;
     // pending layers of k_mh_ws: the 3-layer kernel stages 4*Dp G values per layer in
     // two registers per thread (Dp <= 160), the 2-layer one in four (Dp <= 256); the
     // other MH kernels keep one layer
-    if (const char *e = getenv("D3D_MH_LAYERS")) {
-        c->mh_layers_cfg = atoi(e);
-        c->mh_layers_forced = true;
-    }
+    c->mh_layers_forced = c->mh_layers_opt > 0;
+    c->mh_layers_cfg = c->mh_layers_forced ? c->mh_layers_opt : 2;
     if (c->mh_layers_cfg < 1) c->mh_layers_cfg = 1;
     if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
     if (c->Dp > 160 && c->mh_layers_cfg > 2) c->mh_layers_cfg = 2;
@@ -1227,7 +230,8 @@ int build_colour_lists(d3d_ctx *c) {
         // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
         pt.layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
     }
-    c->mh_layers = c->parts[0].layers;
+    c->mh_layers = 1;
+    for (const d3d_ctx::Part &pt : c->parts) c->mh_layers = std::max(c->mh_layers, pt.layers);
     if (list.size() > c->spx_cap) {
         if (c->spx) (void)hipFree(c->spx);
         c->spx = nullptr;
@@ -1240,6 +244,7 @@ int build_colour_lists(d3d_ctx *c) {
     c->flow_K = 0;
     c->flow_items = 0;
     c->flow_last_cy = c->flow_last_cx = -1;
+#ifdef D3D_EXPERIMENTS
     if (!c->tiled && c->parts.size() == 1 && list.size() <= c->flow_cap_items) {
         const d3d_ctx::Part &pt = c->parts[0];
         std::vector<int4> ents, cols;
@@ -1281,6 +286,7 @@ int build_colour_lists(d3d_ctx *c) {
             HIP_TRY(hipStreamSynchronize(c->stream));  // the host vectors go out of scope
         }
     }
+#endif
     if (!list.empty())
         HIP_TRY(hipMemcpyAsync(c->spx, list.data(), list.size() * sizeof(int4),
                                hipMemcpyHostToDevice, c->stream));
@@ -1289,31 +295,78 @@ int build_colour_lists(d3d_ctx *c) {
     return 0;
 }
 
-}  // namespace
 
-// ---------------------------------------------------------------------------
+// ---- per-context options (d3d_ctx_set_option) -----------------------------------------
+// Every switch of the library is a field of the context.  The environment is only the
+// source of a new context's DEFAULTS (D3D_<KEY>, read once in d3d_ctx_create), so two
+// contexts of one process can run with different settings.  kind: what has to be
+// re-derived when the option changes.
+enum OptKind { OPT_LAUNCH = 0, OPT_MH = 1, OPT_TAPS = 2 };
+struct OptDesc {
+    const char *key, *env;
+    int d3d_ctx::*field;
+    OptKind kind;
+    int lo, hi;
+};
+const OptDesc g_opts[] = {
+    {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer, OPT_MH, 0, 2},
+    {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
+    {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, -1, 1},
+    {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
+    {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
+    {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
+    {"mh_nt", "D3D_MH_NT", &d3d_ctx::mh_nt_opt, OPT_MH, 0, 1024},
+    {"mh_maxit", "D3D_MH_MAXIT", &d3d_ctx::mh_maxit_opt, OPT_MH, -1, 32},
+    {"uniform_ivar", "D3D_UNIFORM_IVAR", &d3d_ctx::uniform_fast_path, OPT_MH, 0, 1},
+    {"conv_rows", "D3D_CONV_ROWS", &d3d_ctx::conv_rows, OPT_LAUNCH, 0, 1},
+    {"conv_hy", "D3D_CONV_HY", &d3d_ctx::conv_hy_opt, OPT_LAUNCH, 0, 1 << 20},
+    {"spatial_sep", "D3D_SPATIAL_SEP", &d3d_ctx::spatial_sep, OPT_TAPS, 0, 1},
+    {"sep_fuse", "D3D_SEP_FUSE", &d3d_ctx::sep_fuse, OPT_LAUNCH, 0, 1},
+    {"spatial_mode", "D3D_SPATIAL_MODE", &d3d_ctx::march_mode, OPT_LAUNCH, 0, 3},
+    {"march_hy", "D3D_MARCH_HY", &d3d_ctx::march_hy_opt, OPT_TAPS, 0, 1 << 20},
+    {"zmajor", "D3D_ZMAJOR", &d3d_ctx::zmajor, OPT_LAUNCH, 0, 1},
+    {"zmajor_hy", "D3D_ZMAJOR_HY", &d3d_ctx::zmajor_hy, OPT_LAUNCH, 1, 1 << 20},
+    {"spectral_dense", "D3D_SPECTRAL_DENSE", &d3d_ctx::spectral_dense, OPT_LAUNCH, 0, 1},
+    {"spatial_nt", "D3D_SPATIAL_NT", &d3d_ctx::sp_nt_opt, OPT_LAUNCH, 0, 1024},
+    {"xcd_remap", "D3D_XCD_REMAP", &d3d_ctx::xcd_remap, OPT_LAUNCH, 0, 1},
+    {"alt_dir", "D3D_ALT_DIR", &d3d_ctx::alt_dir, OPT_LAUNCH, 0, 1},
+    {"stagger", "D3D_STAGGER", &d3d_ctx::stagger, OPT_LAUNCH, 0, 1 << 20},
+#ifdef D3D_EXPERIMENTS
+    // measured-but-not-faster variants of DESIGN.md section 3 (make EXPERIMENTS=1)
+    {"mh_flow", "D3D_MH_FLOW", &d3d_ctx::mh_flow, OPT_MH, 0, 1},
+    {"mh_pair", "D3D_MH_PAIR", &d3d_ctx::mh_pair, OPT_MH, 0, 1},
+    {"spectral_shfl", "D3D_SPECTRAL_SHFL", &d3d_ctx::spectral_shfl, OPT_LAUNCH, 0, 1},
+    {"fuse_lsf", "D3D_FUSE_LSF", &d3d_ctx::fuse_lsf, OPT_TAPS, 0, 1},
+    {"march_pf", "D3D_MARCH_PF", &d3d_ctx::march_pf, OPT_LAUNCH, 0, 3},
+    {"march_one", "D3D_MARCH_ONE", &d3d_ctx::march_one, OPT_LAUNCH, 0, 3},
+    {"march_stamp", "D3D_STAMP", &d3d_ctx::march_stamp, OPT_LAUNCH, 0, 1},
+#endif
+};
 
-namespace {
-bool zmajor_ok(const d3d_ctx *c) {
-    if (getenv("D3D_NO_ZMAJOR")) return false;
-    if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
-    if (c->ntaps > 0 && !c->lsf_dense_ok) return false;
-    switch (c->fw) {
-        case 3: case 5: case 7: case 9: case 11: case 13: case 15: return true;
-        default: return false;
-    }
+const OptDesc *find_opt(const char *key) {
+    for (const OptDesc &o : g_opts)
+        if (!strcmp(o.key, key)) return &o;
+    return nullptr;
 }
 
-template <int FS>
-int launch_spatial_z(d3d_ctx *c, const double *in, double *out) {
-    const int HY = c->zmajor_hy;
-    const long items = (long)c->D * ((c->H + HY - 1) / HY) * ((c->W + 63) / 64);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_z<FS>), dim3((unsigned)((items + 3) / 4)),
-                       dim3(256), 0, c->stream, c->D, c->H, c->W, HY, (const double *)c->fsf, in,
-                       out);
-    HIP_TRY(hipGetLastError());
-    return 0;
+bool opt_value_ok(const OptDesc &o, long v) {
+    if (v < o.lo || v > o.hi) return false;
+    if (!strcmp(o.key, "mh_nt")) return v == 0 || v == 128 || v == 256 || v == 512 || v == 1024;
+    if (!strcmp(o.key, "spatial_nt")) return v == 0 || v == 256 || v == 512 || v == 1024;
+    if (!strcmp(o.key, "mh_maxit")) return v == -1 || v == 0 || v == 4 || v == 8 || v == 16 || v == 32;
+    return true;
 }
+
+// defaults of a new context from the environment (out-of-range values are ignored)
+void options_from_env(d3d_ctx *c) {
+    for (const OptDesc &o : g_opts)
+        if (const char *e = getenv(o.env)) {
+            const long v = atol(e);
+            if (opt_value_ok(o, v)) c->*(o.field) = (int)v;
+        }
+    if (getenv("D3D_NO_ZMAJOR")) c->zmajor = 0;  // (the round-1 spelling)
+}
+
 }  // namespace
 
 extern "C" {
@@ -1373,6 +426,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
         return fail(D3D_ERR_UNSUPPORTED, "spectral depth %d exceeds the kernels' limit of 1024", D);
     }
     c->sp_nt = pick_nt(c->HL);
+    options_from_env(c);
     pick_mh_geometry(c);
 
 #define CTX_TRY(expr)                                                                 \
@@ -1422,6 +476,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
         CTX_TRY(hipMemsetAsync(c->gbuf[b], 0, (size_t)c->slots * c->Dp * sizeof(double), c->stream));
     }
     {
+#ifdef D3D_EXPERIMENTS
         const size_t ncol = (size_t)fh * fw;
         c->flow_LY = H / fh + 3;
         c->flow_LX = W / fw + 3;
@@ -1434,6 +489,7 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
         CTX_TRY(hipMalloc(&c->flow_state, c->flow_state_bytes));
         CTX_TRY(hipMalloc(&c->pair_state, (4 + c->spx_cap) * sizeof(unsigned)));
         CTX_TRY(hipMemsetAsync(c->pair_state, 0, (4 + c->spx_cap) * sizeof(unsigned), c->stream));
+#endif
         CTX_TRY(hipMalloc(&c->flow_err, 16));
         CTX_TRY(hipMemsetAsync(c->flow_err, 0, 16, c->stream));
         int cus = 0;
@@ -1512,8 +568,54 @@ int d3d_timer_stop(d3d_ctx *c, double *ms) {
     return D3D_OK;
 }
 
+static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, double thr);
+
 int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     NEED(c && fsf, D3D_ERR_INVALID, "NULL argument");
+    // host copies: an option that changes the analysis of the taps redoes it from these
+    c->h_fsf.assign(fsf, fsf + (size_t)c->fh * c->fw);
+    c->h_has_lsf = lsf != nullptr;
+    if (lsf) c->h_lsf.assign(lsf, lsf + c->D);
+    c->h_thr = thr;
+    return set_taps_impl(c, c->h_fsf.data(), c->h_has_lsf ? c->h_lsf.data() : nullptr, thr);
+}
+
+int d3d_ctx_set_option(d3d_ctx *c, const char *key, long value) {
+    NEED(c && key, D3D_ERR_INVALID, "NULL argument");
+    const OptDesc *o = find_opt(key);
+    NEED(o, D3D_ERR_INVALID, "unknown option '%s'", key);
+    NEED(opt_value_ok(*o, value), D3D_ERR_INVALID, "option %s: value %ld out of range", key, value);
+    if (c->*(o->field) == (int)value) return D3D_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (o->kind == OPT_MH)  // pending layers belong to the old kernel selection
+        if (int rc = flush_pending(c)) return rc;
+    c->*(o->field) = (int)value;
+    if (o->kind == OPT_MH) {
+        pick_mh_geometry(c);
+        if (c->have_data) return build_colour_lists(c);
+    } else if (o->kind == OPT_TAPS && c->have_taps) {
+        return set_taps_impl(c, c->h_fsf.data(), c->h_has_lsf ? c->h_lsf.data() : nullptr, c->h_thr);
+    }
+    return D3D_OK;
+}
+
+int d3d_ctx_get_option(d3d_ctx *c, const char *key, long *value) {
+    NEED(c && key && value, D3D_ERR_INVALID, "NULL argument");
+    const OptDesc *o = find_opt(key);
+    NEED(o, D3D_ERR_INVALID, "unknown option '%s'", key);
+    *value = c->*(o->field);
+    return D3D_OK;
+}
+
+int d3d_has_experiments(void) {
+#ifdef D3D_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->fsf, fsf, (size_t)c->fh * c->fw * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
@@ -1550,8 +652,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
                         break;
                     }
         }
-        if (const char *e = getenv("D3D_SPATIAL_SEP")) sep = sep && atoi(e) != 0;
-        if (const char *e = getenv("D3D_SEP_FUSE")) c->sep_fuse = atoi(e) != 0;
+        sep = sep && c->spatial_sep != 0;
         c->fsf_sep = sep;
         if (sep)
             HIP_TRY(hipMemcpyAsync(c->sep_uv, uv.data(), uv.size() * sizeof(double),
@@ -1584,14 +685,6 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (const char *e = getenv("D3D_CONV_ROWS")) c->conv_rows = atoi(e);
-    if (const char *e = getenv("D3D_SPATIAL_MODE")) c->march_mode = atoi(e);
-    if (const char *e = getenv("D3D_MARCH_PF")) c->march_pf = atoi(e);
-    if (const char *e = getenv("D3D_MARCH_ONE")) c->march_one = atoi(e);
-    if (const char *e = getenv("D3D_ZMAJOR_HY")) {
-        const int v = atoi(e);
-        if (v >= 1) c->zmajor_hy = v;
-    }
     // Rows per strip of the march kernels: a strip is one wavefront's worth of z
     // (64 / HL strips per wavefront when the spectrum is shorter), the chip holds
     // two such wavefronts per SIMD, and a strip costs HY + FS - 1 row steps.  Take
@@ -1613,10 +706,7 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
             }
         }
     }
-    if (const char *e = getenv("D3D_MARCH_HY")) {
-        const int v = atoi(e);
-        if (v >= 1) c->march_hy = v;
-    }
+    if (c->march_hy_opt >= 1) c->march_hy = c->march_hy_opt;
     std::vector<int> shift;
     std::vector<double> weight;
     if (lsf) {
@@ -1640,9 +730,6 @@ int d3d_set_taps(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     // dense form for the fused epilogue: out[k] = sum_j wl[j] v[(k + j - RL) mod N]
     c->lsf_fusable = false;
     c->lsf_dense_ok = false;
-    if (const char *e = getenv("D3D_FUSE_LSF")) c->fuse_lsf = atoi(e);
-    if (const char *e = getenv("D3D_SPECTRAL_DENSE")) c->spectral_dense = atoi(e);
-    if (const char *e = getenv("D3D_SPECTRAL_SHFL")) c->spectral_shfl = atoi(e);
     if (c->ntaps && c->N == c->D && c->D >= 4 * d3d::LSF_RL) {
         std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
         bool ok = true;
@@ -1839,33 +926,7 @@ int d3d_stage_convolve(d3d_ctx *c) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(c->have_taps, D3D_ERR_STATE, "taps not set");
     HIP_TRY(hipSetDevice(c->device));
-    if (zmajor_ok(c)) {
-        // both passes in the reference layout, lanes along x: no layout change
-        const double *src = c->stage;
-        if (c->ntaps > 0) {
-            hipLaunchKernelGGL(d3d::k_spectral_z, dim3((unsigned)((c->HW + 255) / 256)), dim3(256), 0,
-                               c->stream, c->D, c->HW, (const double *)c->lsf_dense,
-                               (const double *)c->stage, c->stage2);
-            HIP_TRY(hipGetLastError());
-            src = c->stage2;
-        }
-        double *dst = (src == c->stage) ? c->stage2 : c->stage;
-        int rc;
-        switch (c->fw) {
-            case 3: rc = launch_spatial_z<3>(c, src, dst); break;
-            case 5: rc = launch_spatial_z<5>(c, src, dst); break;
-            case 7: rc = launch_spatial_z<7>(c, src, dst); break;
-            case 9: rc = launch_spatial_z<9>(c, src, dst); break;
-            case 11: rc = launch_spatial_z<11>(c, src, dst); break;
-            case 13: rc = launch_spatial_z<13>(c, src, dst); break;
-            default: rc = launch_spatial_z<15>(c, src, dst); break;
-        }
-        if (rc) return rc;
-        if (dst != c->stage)
-            HIP_TRY(hipMemcpyAsync(c->stage, dst, (size_t)c->D * c->HW * sizeof(double),
-                                   hipMemcpyDeviceToDevice, c->stream));
-        return D3D_OK;
-    }
+    if (zmajor_ok(c)) return launch_zmajor_convolve(c);
     // general taps: through the spectrum-contiguous slot kernels
     int rc = to_device_layout(c, c->stage, c->slot[D3D_SLOT_TMP0]);
     if (rc) return rc;
@@ -2075,10 +1136,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         if (n_real <= 0) continue;
         const int ka = ord++;
         if (deferred) c->pend_part = pi;  // fill_mh_args takes the domain from it
-        if (pairs && c->lay_n == 1 && ka + 1 < c->flow_K) {
 #ifdef D3D_EXPERIMENTS
+        if (pairs && c->lay_n == 1 && ka + 1 < c->flow_K) {
             if (c->stampbuf) goto single;  // phase stamps are per colour launch
-#endif
             int rc = launch_mh_pair(c, ka, sweep);
             if (rc) return rc;
             // skip colour B in this loop
@@ -2087,8 +1147,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
             ++ord;
             continue;
         }
-#ifdef D3D_EXPERIMENTS
     single:
+#else
+        (void)pairs;
 #endif
         d3d::MHArgs P;
         fill_mh_args(c, P);
@@ -2105,7 +1166,7 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
             // the launch that finds `layers` layers pending applies them for good
             P.write_back = (c->lay_n >= pt.layers) ? 1 : 0;
             const int g_cur = pend_free_buf(c);
-            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep);
+            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep, pt.layers);
             if (rc) return rc;
             if (P.write_back) c->lay_n = 0;
             // this launch's updates are the newest pending layer (local residues)
@@ -2170,12 +1231,15 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                       c->cube_elems * sizeof(double) < (size_t(1) << 31);
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
         const uint32_t rs = (uint32_t)s + c->sweep_origin;
+#ifdef D3D_EXPERIMENTS
         if (flow) {
             c->pend_part = 0;
             int rc = launch_mh_flow(c, rs);
             if (rc) return rc;
             c->pend_part = 0;
-        } else {
+        } else
+#endif
+        {
             for (int ph = 0; ph < n_phases; ++ph) {
                 int rc = run_phase(c, ph, rs);
                 if (rc) return rc;
@@ -2418,15 +1482,7 @@ int d3d_apply_updates(d3d_ctx *c, int n, const double *records) {
                            hipMemcpyHostToDevice, c->stream));
     d3d::MHArgs P;
     fill_mh_args(c, P);
-    const size_t lds = (size_t)(2 * c->N + c->Dp) * sizeof(double);
-    if (c->HL <= 256) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<256>), dim3((unsigned)n), dim3(256),
-                           lds, c->stream, P, (const double *)c->recbuf, n);
-    } else {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<1024>), dim3((unsigned)n),
-                           dim3(1024), lds, c->stream, P, (const double *)c->recbuf, n);
-    }
-    HIP_TRY(hipGetLastError());
+    if (int rc = launch_apply_updates(c, P, (const double *)c->recbuf, n)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return D3D_OK;
 }
@@ -2613,30 +1669,31 @@ int d3d_halo_plan(d3d_ctx *c, int plan, int n, const int *entries) {
         ro += e.recv_n;
         v.push_back(e);
     }
-    if ((int)c->plans.size() <= plan) c->plans.resize(plan + 1);
-    c->plans[plan] = v;
     HIP_TRY(hipStreamSynchronize(c->stream));  // nobody may still use the old buffers
-    if (so > c->halo_send_cap) {
-        for (int b = 0; b < d3d_ctx::STREAM_NB; ++b) {
-        if (c->snap_dev[b]) (void)hipFree(c->snap_dev[b]);
-        if (c->snap_host[b]) (void)hipHostFree(c->snap_host[b]);
-        if (c->snap_ready[b]) (void)hipEventDestroy(c->snap_ready[b]);
-        if (c->snap_done[b]) (void)hipEventDestroy(c->snap_done[b]);
+    // Grow the buffers FIRST; the plan goes live only when both exist, so that a failed
+    // allocation leaves the old plan and the old buffers as they were.
+    double *ns = nullptr, *nr = nullptr;
+    if (so > c->halo_send_cap) HIP_TRY(hipMalloc(&ns, so * sizeof(double)));
+    if (ro > c->halo_recv_cap) {
+        const hipError_t e = hipMalloc(&nr, ro * sizeof(double));
+        if (e != hipSuccess) {
+            if (ns) (void)hipFree(ns);
+            return fail(D3D_ERR_HIP, "hipMalloc of the halo receive buffer failed: %s",
+                        hipGetErrorString(e));
+        }
     }
-    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->halo_send) (void)hipFree(c->halo_send);
-        c->halo_send = nullptr;
-        c->halo_send_cap = 0;
-        HIP_TRY(hipMalloc(&c->halo_send, so * sizeof(double)));
+    if (ns) {
+        if (c->halo_send) (void)hipFree(c->halo_send);
+        c->halo_send = ns;
         c->halo_send_cap = so;
     }
-    if (ro > c->halo_recv_cap) {
+    if (nr) {
         if (c->halo_recv) (void)hipFree(c->halo_recv);
-        c->halo_recv = nullptr;
-        c->halo_recv_cap = 0;
-        HIP_TRY(hipMalloc(&c->halo_recv, ro * sizeof(double)));
+        c->halo_recv = nr;
         c->halo_recv_cap = ro;
     }
+    if ((int)c->plans.size() <= plan) c->plans.resize(plan + 1);
+    c->plans[plan] = v;
     return D3D_OK;
 }
 
@@ -2752,10 +1809,11 @@ int d3d_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma
     HIP_TRY(hipSetDevice(c->device));
     double *buf = nullptr;
     HIP_TRY(hipMalloc(&buf, (size_t)n * sizeof(double)));
-    const long threads = wave_mode ? n * 64 : n;
-    hipLaunchKernelGGL(d3d::k_rtnorm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
-                       n, lo, hi, mu, sigma, seed, wave_mode, buf);
-    hipError_t e = hipGetLastError();
+    if (int rc = launch_rtnorm(c, n, lo, hi, mu, sigma, seed, wave_mode, buf)) {
+        (void)hipFree(buf);
+        return rc;
+    }
+    hipError_t e = hipSuccess;
     if (e == hipSuccess)
         e = hipMemcpyAsync(out, buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -2773,3 +1831,4 @@ int d3d_colour_count(d3d_ctx *c, int colour, int *count) {
 }
 
 }  // extern "C"
+

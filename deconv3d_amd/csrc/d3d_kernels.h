@@ -21,7 +21,7 @@ namespace d3d {
 // ------------------------------------------------------------------------- //
 
 // (D, HW) host layout -> (HW, Dp) device layout, zero padded.  32x32 LDS tile.
-__global__ __launch_bounds__(256) void k_to_device_layout(const double *__restrict__ src,
+static __global__ __launch_bounds__(256) void k_to_device_layout(const double *__restrict__ src,
                                                            double *__restrict__ dst, int D,
                                                            int Dp, long HW) {
     __shared__ double tile[32][33];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_to_device_layout(const double *__restri
 }
 
 // (HW, Dp) device layout -> (D, HW) host layout.
-__global__ __launch_bounds__(256) void k_to_host_layout(const double *__restrict__ src,
+static __global__ __launch_bounds__(256) void k_to_host_layout(const double *__restrict__ src,
                                                          double *__restrict__ dst, int D, int Dp,
                                                          long HW) {
     __shared__ double tile[32][33];
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_to_host_layout(const double *__restrict
 
 // data/variance fix-ups of lib/run.py:171-200 + SURVEY appendix A, elementwise
 // in host layout: var==0 -> 1e12; NaN voxel -> data 0, 1/var 0.
-__global__ void k_prepare_data(double *__restrict__ data, double *__restrict__ ivar,
+static __global__ void k_prepare_data(double *__restrict__ data, double *__restrict__ ivar,
                                const double *__restrict__ var, double var_scalar, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(NT) void k_spatial_generic(SpatialArgs A,
 // 2*LSF_RL+1 channels around the current one in registers:
 //   out[k] = sum_j wl[j] * in[(k + j - RL) mod D]       (D a power of two)
 // The window rotates at compile time (the march is unrolled by its length).
-__global__ __launch_bounds__(256) void k_spectral_z(int D, long HW, const double *__restrict__ wl,
+static __global__ __launch_bounds__(256) void k_spectral_z(int D, long HW, const double *__restrict__ wl,
                                                     const double *__restrict__ in,
                                                     double *__restrict__ out) {
     constexpr int RL = LSF_RL, NW = 2 * LSF_RL + 1;
@@ -1434,7 +1434,7 @@ __device__ __forceinline__ double wave_sum_dpp63(double v) {
 
 // out[sp] = 0.5 * sum_z err^2 * ivar (lib/run.py:423 per spectrum); one wave
 // per spaxel.
-__global__ __launch_bounds__(256) void k_chi2_map(const double *__restrict__ err,
+static __global__ __launch_bounds__(256) void k_chi2_map(const double *__restrict__ err,
                                                    const double *__restrict__ ivar,
                                                    double *__restrict__ out, int HL, int Dp,
                                                    long nspax) {
@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_chi2_map(const double *__restrict__ err
 }
 
 // Deterministic single-block sum of n doubles.
-__global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long n,
+static __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ v, long n,
                                                double *__restrict__ out) {
     __shared__ double part[16];
     double acc = 0.0;
@@ -1629,27 +1629,15 @@ struct MHProposal {
     uint32_t gsp;  // global spaxel index (Philox key)
 };
 
-// lib/run.py:369-388: Cauchy jump from the current parameters and bounds test.
-// Every calling thread computes the same numbers.
-__device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32_t sweep) {
+// lib/run.py:369-388: Cauchy jump from the given current parameters and bounds test
+// (the arithmetic of mh_propose; k_mh_chain calls it with parameters it keeps in LDS).
+__device__ __forceinline__ MHProposal mh_propose_from(const MHArgs &P, double a_old, double c_old,
+                                                      double w_old, uint32_t gsp, uint32_t sweep) {
     MHProposal q;
-    const int ly = sp / P.W, lx = sp - ly * P.W;
-    q.gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
-    if (P.ext_lines) {
-        // proposal made on the host: only the amplitude, the bounds verdict and
-        // log(u) come in; the lines themselves are read by the caller
-        const double *in3 = P.ext_in + (long)blockIdx.x * 3;
-        q.a_old = in3[0];
-        q.c_old = q.w_old = 0.0;
-        q.pn[0] = q.a_old;
-        q.pn[1] = q.pn[2] = 0.0;
-        q.oob = in3[1] != 0.0;
-        q.log_u = in3[2];
-        return q;
-    }
-    q.a_old = P.params[(long)sp * 3 + 0];
-    q.c_old = P.params[(long)sp * 3 + 1];
-    q.w_old = P.params[(long)sp * 3 + 2];
+    q.gsp = gsp;
+    q.a_old = a_old;
+    q.c_old = c_old;
+    q.w_old = w_old;
     double u_acc = 0.5;
     if (P.probe) {
         q.pn[0] = P.probe_p[0];
@@ -1674,6 +1662,28 @@ __device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32
     return q;
 }
 
+// lib/run.py:369-388: Cauchy jump from the current parameters and bounds test.
+// Every calling thread computes the same numbers.
+__device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32_t sweep) {
+    MHProposal q;
+    const int ly = sp / P.W, lx = sp - ly * P.W;
+    q.gsp = (uint32_t)((ly + P.gy0) * P.Wg + (lx + P.gx0));
+    if (P.ext_lines) {
+        // proposal made on the host: only the amplitude, the bounds verdict and
+        // log(u) come in; the lines themselves are read by the caller
+        const double *in3 = P.ext_in + (long)blockIdx.x * 3;
+        q.a_old = in3[0];
+        q.c_old = q.w_old = 0.0;
+        q.pn[0] = q.a_old;
+        q.pn[1] = q.pn[2] = 0.0;
+        q.oob = in3[1] != 0.0;
+        q.log_u = in3[2];
+        return q;
+    }
+    return mh_propose_from(P, P.params[(long)sp * 3 + 0], P.params[(long)sp * 3 + 1],
+                           P.params[(long)sp * 3 + 2], q.gsp, sweep);
+}
+
 // LSF-convolved unit lines of channel ch from the zero-extended unit lines in
 // gO / gN (closed form of convolve_1d, lib/convolution.py:89-120).
 __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const double *gN, int ch,
@@ -1696,124 +1706,147 @@ __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const 
     *EN = en;
 }
 
-// From the per-channel window sums to the new state.  ch = this thread's
-// channel (threads with ch >= D carry zeros), `first` = index of the first of
-// the nw wavefronts that call this (they are consecutive).  Contains two block
-// barriers that every thread of the workgroup must reach.  Returns false in
-// probe mode and to non-callers.
+// From the per-channel window sums to the new state, in three steps (mh_finish strings
+// them together; k_mh_chain gives the decision to a wavefront of its own):
+//   mh_channel_sums   thread <-> channel: the seven sums over the channels of one
+//                     wavefront, into S.sum[wave][0..6]
+//   mh_decide_wave    ONE wavefront (every lane the same numbers): totals, accept,
+//                     Gibbs draw; state written, verdict left in LDS
+//   mh_update_coeff   thread <-> channel: the residual update coefficient G[z]
+__device__ __forceinline__ void mh_channel_sums(const MHArgs &P, const MHShared &S,
+                                                const MHProposal &q, int ch, int G, double EO,
+                                                double EN, int first) {
+    const int Dp = P.Dp, D = P.D;
+    double sums[7];
+    const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
+    const double Lo = q.a_old * EO;
+    double Az = 0.0, Bz = 0.0, Cz = 0.0;
+    if (ch < D) {
+        for (int gg = 0; gg < G; ++gg) {
+            const double *r = S.red + (size_t)gg * 3 * Dp + ch;
+            Az += r[0];
+            Bz += r[Dp];
+            Cz += r[2 * Dp];
+        }
+    }
+    const double d = Lo - a_new * EN;  // old minus new contribution per unit f
+    const double ulB = Az + Lo * Bz;   // sum_pos f v ul
+    sums[0] = d * Az;
+    sums[1] = d * d * Bz;
+    sums[2] = Cz;
+    sums[3] = EO * EO * Bz;
+    sums[4] = EO * ulB;
+    sums[5] = EN * EN * Bz;
+    sums[6] = EN * ulB;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp63(sums[k]);
+    const int wave = (threadIdx.x >> 6) - first;
+    if ((threadIdx.x & 63) == 63) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
+    }
+}
+
+// One wavefront takes the decision (every lane the same numbers) and leaves
+// {accepted, amplitude} in the spare slots behind the wave sums: the fp64
+// special functions of the truncated normal would otherwise be issued by
+// every wavefront of every resident workgroup at the same moment.
+__device__ __forceinline__ void mh_decide_wave(const MHArgs &P, const MHShared &S,
+                                               const MHProposal &q, int sp, uint32_t sweep, int nw,
+                                               const U2 &u_gibbs) {
+    double *verdict = S.sum + 8 * nw;
+    double tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double t = 0.0;
+        for (int wv = 0; wv < nw; ++wv) t += S.sum[wv * 8 + k];
+        tot[k] = t;
+    }
+    const double ar_old = 0.5 * tot[2];
+    const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
+    const bool lead = (threadIdx.x & 63) == 0;
+    if (P.probe) {
+        if (lead) {
+            P.probe_out[0] = ar_old;
+            P.probe_out[1] = ar_old - delta;
+            P.probe_out[2] = delta;
+            P.probe_out[3] = tot[3];
+            P.probe_out[4] = tot[4];
+        }
+        return;
+    }
+    // ---- MH accept (lib/run.py:435-445) --------------------------------
+    const bool accept = (q.log_u < delta) && !q.oob;
+    // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
+    const double s_ee = accept ? tot[5] : tot[3];
+    const double s_eu = accept ? tot[6] : tot[4];
+    // ---- Gibbs draw of the amplitude (lib/run.py:456-499) --------------
+    double r;
+    if (P.ext_lines && !P.ext_gibbs) {
+        r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
+    } else {
+        const double ro = P.ra / (1.0 + P.ra * s_ee);
+        const double mu = ro * s_eu;
+        uint32_t blk = BLK_GIBBS;
+        r = truncated_normal<true>(P.min_b[0], P.max_b[0], mu, sqrt(ro), u_gibbs, P.seed, q.gsp,
+                                   sweep, &blk);
+    }
+    if (lead) {
+        verdict[0] = accept ? 1.0 : 0.0;
+        verdict[1] = r;
+        if (P.ext_lines) {
+            double *o3 = P.ext_out + (long)blockIdx.x * 3;
+            o3[0] = accept ? 1.0 : 0.0;
+            o3[1] = r;
+            o3[2] = delta;
+        } else {
+            if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
+                P.prev[(long)sp * 3 + 0] = q.a_old;
+                P.prev[(long)sp * 3 + 1] = q.c_old;
+                P.prev[(long)sp * 3 + 2] = q.w_old;
+            }
+            P.params[(long)sp * 3 + 0] = r;
+            P.params[(long)sp * 3 + 1] = accept ? q.pn[1] : q.c_old;
+            P.params[(long)sp * 3 + 2] = accept ? q.pn[2] : q.w_old;
+        }
+        P.dlog[sp] = delta;
+        if (accept) atomicAdd(P.accepted, 1ULL);
+    }
+}
+
+// err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
+__device__ __forceinline__ double mh_update_coeff(const MHArgs &P, const MHShared &S,
+                                                  const MHProposal &q, int ch, double EO, double EN,
+                                                  int nw) {
+    const double *verdict = S.sum + 8 * nw;
+    const bool accept = verdict[0] != 0.0;
+    const double r = verdict[1];
+    return (ch < P.D) ? residual_coeff(q.a_old, EO, r, accept ? EN : EO) : 0.0;
+}
+
+// ch = this thread's channel (threads with ch >= D carry zeros), `first` = index of the
+// first of the nw wavefronts that call this (they are consecutive).  Contains two block
+// barriers that every thread of the workgroup must reach.  Returns false in probe mode
+// and to non-callers.
 __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, const MHProposal &q,
                                           int sp, uint32_t sweep, int ch, int G, double EO,
                                           double EN, int first, int nw, bool caller,
                                           double *Gz_out, const U2 *u_pre = nullptr) {
-    const int Dp = P.Dp, D = P.D;
-    double sums[7] = {0, 0, 0, 0, 0, 0, 0};
-    const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
-    const double Lo = q.a_old * EO;
     // the uniforms of the Gibbs draw depend on nothing the window pass produces:
     // drawn here, ahead of the barrier, they are off the critical tail
     U2 u_gibbs = {0.5, 0.5};
     if (caller) {
         u_gibbs = u_pre ? *u_pre : philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
-        double Az = 0.0, Bz = 0.0, Cz = 0.0;
-        if (ch < D) {
-            for (int gg = 0; gg < G; ++gg) {
-                const double *r = S.red + (size_t)gg * 3 * Dp + ch;
-                Az += r[0];
-                Bz += r[Dp];
-                Cz += r[2 * Dp];
-            }
-        }
-        const double d = Lo - a_new * EN;  // old minus new contribution per unit f
-        const double ulB = Az + Lo * Bz;   // sum_pos f v ul
-        sums[0] = d * Az;
-        sums[1] = d * d * Bz;
-        sums[2] = Cz;
-        sums[3] = EO * EO * Bz;
-        sums[4] = EO * ulB;
-        sums[5] = EN * EN * Bz;
-        sums[6] = EN * ulB;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp63(sums[k]);
-        const int wave = (threadIdx.x >> 6) - first;
-        if ((threadIdx.x & 63) == 63) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
-        }
+        mh_channel_sums(P, S, q, ch, G, EO, EN, first);
     }
     __syncthreads();
-    // One wavefront takes the decision (every lane the same numbers) and leaves
-    // {accepted, amplitude} in the spare slots behind the wave sums: the fp64
-    // special functions of the truncated normal would otherwise be issued by
-    // every wavefront of every resident workgroup at the same moment.
-    double *verdict = S.sum + 8 * nw;
-    if (caller && (int)(threadIdx.x >> 6) == first) {
-        double tot[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            double t = 0.0;
-            for (int wv = 0; wv < nw; ++wv) t += S.sum[wv * 8 + k];
-            tot[k] = t;
-        }
-        const double ar_old = 0.5 * tot[2];
-        const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
-        const bool lead = (threadIdx.x & 63) == 0;
-        if (P.probe) {
-            if (lead) {
-                P.probe_out[0] = ar_old;
-                P.probe_out[1] = ar_old - delta;
-                P.probe_out[2] = delta;
-                P.probe_out[3] = tot[3];
-                P.probe_out[4] = tot[4];
-            }
-        } else {
-            // ---- MH accept (lib/run.py:435-445) --------------------------------
-            const bool accept = (q.log_u < delta) && !q.oob;
-            // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
-            const double s_ee = accept ? tot[5] : tot[3];
-            const double s_eu = accept ? tot[6] : tot[4];
-            // ---- Gibbs draw of the amplitude (lib/run.py:456-499) --------------
-            double r;
-            if (P.ext_lines && !P.ext_gibbs) {
-                r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
-            } else {
-                const double ro = P.ra / (1.0 + P.ra * s_ee);
-                const double mu = ro * s_eu;
-                uint32_t blk = BLK_GIBBS;
-                r = truncated_normal<true>(P.min_b[0], P.max_b[0], mu, sqrt(ro), u_gibbs, P.seed,
-                                           q.gsp, sweep, &blk);
-            }
-            if (lead) {
-                verdict[0] = accept ? 1.0 : 0.0;
-                verdict[1] = r;
-                if (P.ext_lines) {
-                    double *o3 = P.ext_out + (long)blockIdx.x * 3;
-                    o3[0] = accept ? 1.0 : 0.0;
-                    o3[1] = r;
-                    o3[2] = delta;
-                } else {
-                    if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
-                        P.prev[(long)sp * 3 + 0] = q.a_old;
-                        P.prev[(long)sp * 3 + 1] = q.c_old;
-                        P.prev[(long)sp * 3 + 2] = q.w_old;
-                    }
-                    P.params[(long)sp * 3 + 0] = r;
-                    P.params[(long)sp * 3 + 1] = accept ? q.pn[1] : q.c_old;
-                    P.params[(long)sp * 3 + 2] = accept ? q.pn[2] : q.w_old;
-                }
-                P.dlog[sp] = delta;
-                if (accept) atomicAdd(P.accepted, 1ULL);
-            }
-        }
-    }
+    if (caller && (int)(threadIdx.x >> 6) == first) mh_decide_wave(P, S, q, sp, sweep, nw, u_gibbs);
     __syncthreads();
     if (!caller || P.probe) {
         *Gz_out = 0.0;
         return false;
     }
-    const bool accept = verdict[0] != 0.0;
-    const double r = verdict[1];
-    // err_final = ul - f*E_end*r = e + f*(a_old*E_old - r*E_end)  (lib/run.py:508-515)
-    *Gz_out = (ch < D) ? residual_coeff(q.a_old, EO, r, accept ? EN : EO) : 0.0;
+    *Gz_out = mh_update_coeff(P, S, q, ch, EO, EN, nw);
     return true;
 }
 
@@ -2540,9 +2573,426 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_run<NS, UV, false, U, M, false, true, NTV>(P, S, I, sweep, blockIdx.x, &pre);
 }
 
+// ---- whole sweeps of a small part in ONE launch: persistent workgroups ----------------------
+//
+// A colour launch that does not fill the chip is a latency chain: setup,
+// proposal -> lines -> LSF on one wavefront, the window's round trips, the decision, the kernel
+// boundary -- 12-15 us per colour however few windows it holds, 121 times per sweep.  k_mh_chain
+// keeps ONE workgroup per lattice slot resident for all colours of all sweeps of the launch:
+//
+//   * slot (iy, ix) owns the window centres [sy0 + iy*fh, +fh) x [sx0 + ix*fw, +fw): exactly
+//     one lattice point of every colour class, so the windows of one colour -- real spaxels and
+//     the virtual positions that only apply pending updates -- still tile the part's domain;
+//   * the residual keeps ONE pending layer, as k_mh_ws with one layer does: colour k applies
+//     colour k-1's update e += f G while it accumulates its own window sums, and stores e;
+//   * a window of colour k depends on the <= 4 windows of colour k-1 that intersect it, through
+//     two monotonic epoch flags per slot: flag1 = "residual stores of colour E complete"
+//     (raised while the slot's decision is still being taken) and flag2 = "G row of colour E
+//     published".  A workgroup loads its window as soon as its predecessors' flag1 is up --
+//     during their decisions -- and holds it in REGISTERS (UT positions per thread); when
+//     their flag2 follows, the four G rows (4 KiB) are all that is left on the critical path:
+//     decision -> G row -> flag -> G rows -> apply + accumulate from registers -> decision;
+//   * everything that does not depend on the window is taken off that path: the proposals of
+//     a whole sweep (Philox, tan, log: they depend on nothing the sweep changes) are computed
+//     at its start, one colour per thread; position table, unit lines and their LSF
+//     convolution of colour k+1 are built by the streaming wavefronts while the extra
+//     wavefront takes colour k's decision;
+//   * hand-off (cdna_hip_programming.md Guideline 16, the all-sc1 form): every residual and
+//     G-row byte is stored write-through (sc1) and loaded sc1; every storing wavefront
+//     drains (vmcnt(0)) and counts itself in LDS, the last one raises the flag (an sc1
+//     store); every wavefront that loads handed-off bytes polls the flags itself first.
+//
+// Same windows, same order of the same operations as one k_mh_ws<NS> launch per colour with
+// one pending layer: bit-identical chains (tests/test_gpu_chain.py).  Every spin has a
+// wall-clock bound that raises *F.err and lets the grid drain; the host launches the kernel
+// only when all slots are resident at once (one workgroup per CU).
+struct MHChain {
+    const int2 *cols;   // [K] LOCAL residues (ly, lx) of the part's active colours, in sweep order
+    unsigned *flag1;    // [slots] epoch up to which the slot's residual stores are complete
+    unsigned *flag2;    // [slots] epoch up to which the slot's G rows are published
+    unsigned *err;      // sticky: a wait timed out
+    double *G;          // [2][K][slots][Dp] G rows by (sweep parity, colour ordinal, slot)
+    double *Gout;       // the LAST colour's rows in the library's regular indexing
+                        // ((y/fh)*slots_x + x/fw): the pending layer the launch leaves
+    int K, n_sy, n_sx;  // active colours; slot grid
+    int sy0, sx0;       // window centres of slot (0,0) start here
+    int py0, py1, px0, px1;  // the part's rectangle: its unmasked spaxels are the real ones
+    unsigned base;      // every flag holds `base` when the launch starts
+    uint32_t sweep0;    // Philox sweep number of the first sweep
+    int n_sweeps;
+    int zigzag;
+};
+
+__device__ __forceinline__ int covering_lattice(int q, int c, int per, int hw) {
+    int m = (q - c) % per;
+    if (m < 0) m += per;
+    int s = q - m;
+    if (q - s > hw) s += per;
+    return s;
+}
+
+// spin until *addr has reached epoch `want` (monotonic, wrap-safe); every active lane polls
+// its own word.  false: timed out (2 s) or another workgroup did -- *err is set.
+__device__ __forceinline__ bool chain_wait(const unsigned *addr, unsigned want, unsigned *err) {
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spins = 1;; ++spins) {
+        const unsigned v = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)(v - want) >= 0) return true;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63) == 0) {
+            if (wall_clock64() - t0 > 200000000ULL) {  // 2 s at 100 MHz: give up, let the grid drain
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        }
+    }
+}
+
+constexpr int MH_PROP_DOUBLES = (sizeof(MHProposal) + 7) / 8;
+
+__host__ __device__ inline size_t mh_chain_lds_doubles(int NS, int HL, int Dp, int N, int npos,
+                                                       int K) {
+    // k_mh_ws's regions | proposals of a sweep | parameters after each colour's update | control
+    return mh_ws_lds_doubles(NS, HL, Dp, N, npos, 1) + (size_t)K * (MH_PROP_DOUBLES + 3) + 4;
+}
+
+// lattice point of residue r in [lo, lo + per)
+__device__ __forceinline__ int chain_lattice_point(int lo, int r, int per) {
+    int m = (r - lo) % per;
+    if (m < 0) m += per;
+    return lo + m;
+}
+
+#ifdef D3D_EXPERIMENTS
+#define D3D_CHAIN_STAMP(j)                                                             \
+    do {                                                                               \
+        if (P.stamp && si == F.n_sweeps - 1 && tid == 0)                               \
+            P.stamp[((long)blockIdx.x * F.K + k) * 8 + (j)] = wall_clock64();          \
+    } while (0)
+#else
+#define D3D_CHAIN_STAMP(j)
+#endif
+
+template <int NS, bool UV, int UT>
+__global__ __launch_bounds__(NS + 64) void k_mh_chain(MHArgs P, MHChain F) {
+    extern __shared__ double smem[];
+    constexpr int NT = NS + 64;
+    constexpr int NW = NS / 64;  // streaming wavefronts 0 .. NW-1; wavefront NW decides
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int HL = P.HL, Dp = P.Dp, N = P.N, npos = P.npos;
+    const int G = NS / HL;
+    const int fh = P.fh, fw = P.fw, fhh = (fh - 1) / 2, fhw = (fw - 1) / 2;
+    const MHShared S = mh_carve(smem, NS, HL, Dp, N, npos, 1);
+    double *sEN = S.sum + 8 * NW + 8;
+    double *xb = smem + mh_ws_lds_doubles(NS, HL, Dp, N, npos, 1);
+    MHProposal *sprop = reinterpret_cast<MHProposal *>(xb);   // [K]
+    double *snew = xb + (size_t)F.K * MH_PROP_DOUBLES;        // [K][3]
+    unsigned *sctl = reinterpret_cast<unsigned *>(snew + 3 * (size_t)F.K);  // drain counters
+    const bool streamer = tid < NS;
+    const int g = tid / HL, zl = tid - g * HL;  // streaming thread: position group, z-pair
+    const bool has_window = streamer && g < G;
+    const int slots = F.n_sy * F.n_sx;
+    const int slot = blockIdx.x;
+    const int iy = slot / F.n_sx, ix = slot - iy * F.n_sx;
+    const int ylo = F.sy0 + iy * fh, xlo = F.sx0 + ix * fw;
+    const int nstore = (Dp + 63) / 64;  // wavefronts that store the G row
+
+    for (int p = tid; p < npos; p += NT) S.fsf[p] = P.fsf[p];
+    if (tid < 4) sctl[tid] = 0u;
+
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    union { double2 d; v4u i; } cv;
+    // raw buffer over SLOT_ERR (the launcher checks that it is < 2 GiB); aux 16 = sc1
+    const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        P.err, 0, (int)((long)P.H * P.W * Dp * 8), 0x00020000);
+    // the padding channel of an odd depth carries 1/var = 0
+    const double2 vu = make_double2(P.ivar_uniform, (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
+
+    // geometry of a colour at this slot; everything here is uniform over the workgroup
+    struct Geo {
+        int y, x, present, real, have_pred, rev, pk, pring;
+        int py0l, py1l, px0l, px1l;  // lattice points of the previous colour at the window's corners
+        MHWsItem I;
+    };
+    auto geometry = [&](int si, int k) {
+        Geo c;
+        const int2 col = F.cols[k];
+        c.y = chain_lattice_point(ylo, col.x, fh);
+        c.x = chain_lattice_point(xlo, col.y, fw);
+        // (the window reaches the domain's upper/left edge by construction of the slot grid)
+        c.present = (c.y - fhh < P.dy1) && (c.x - fhw < P.dx1);
+        c.real = 0;
+        if (c.present && c.y >= F.py0 && c.y < F.py1 && c.x >= F.px0 && c.x < F.px1)
+            c.real = P.mask[c.y * P.W + c.x] != 0;
+        c.have_pred = (si | k) != 0;
+        c.pk = k ? k - 1 : F.K - 1;
+        c.pring = k ? (si & 1) : ((si + 1) & 1);
+        c.rev = (F.zigzag && (k & 1)) ? 1 : 0;
+        const int2 pc = F.cols[c.pk];
+        c.py0l = covering_lattice(max(c.y - fhh, P.dy0), pc.x, fh, fhh);
+        c.py1l = covering_lattice(min(c.y + fhh, P.dy1 - 1), pc.x, fh, fhh);
+        c.px0l = covering_lattice(max(c.x - fhw, P.dx0), pc.y, fw, fhw);
+        c.px1l = covering_lattice(min(c.x + fhw, P.dx1 - 1), pc.y, fw, fhw);
+        c.I.y = c.y;
+        c.I.x = c.x;
+        c.I.real = c.real;
+        c.I.n_lay = c.have_pred ? 1 : 0;
+        c.I.write_back = 1;
+        c.I.rev = c.rev;
+#pragma unroll
+        for (int j = 0; j < MH_LAYERS; ++j) {
+            c.I.lay_cy[j] = pc.x;
+            c.I.lay_cx[j] = pc.y;
+            c.I.lay_G[j] = nullptr;
+        }
+        c.I.Gcur = nullptr;
+        mh_ws_preds<1>(P, c.I);
+        return c;
+    };
+    // slot of a lattice point of the slot grid
+    auto slot_of = [&](int sy, int sx) { return ((sy - F.sy0) / fh) * F.n_sx + (sx - F.sx0) / fw; };
+
+    // position table (by the threads t0 .. t0+nt-1), and unit lines + their LSF convolution
+    // (by ONE wavefront: wave-private, no block barrier) of a colour
+    auto build_table = [&](const Geo &c, int t0, int nt) {
+        if (!c.present) return;
+        for (int p = tid - t0; p < npos; p += nt) {
+            const int dy = p / fw, dx = p - dy * fw;
+            const int yy = c.y + dy - fhh, xx = c.x + dx - fhw;
+            const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
+            S.pos[2 * p] = inside ? yy * P.W + xx : -1;
+            int code = -1;
+            if (inside && c.have_pred) {
+                const int sy = covering_coord(yy, c.I.lay_cy[0], fh, fhh, P.H);
+                const int sx = covering_coord(xx, c.I.lay_cx[0], fw, fhw, P.W);
+                if (sy >= 0 && sx >= 0)
+                    code = ((yy - sy + fhh) * fw + (xx - sx + fhw)) |
+                           (((sy == c.I.psy0[0] ? 0 : 2) + (sx == c.I.psx0[0] ? 0 : 1)) << 16);
+            }
+            S.pos[2 * p + 1] = code;
+        }
+    };
+    auto build_lines = [&](const Geo &c, int k) {
+        if (!c.real) return;
+        const MHProposal q = sprop[k];
+        for (int j = lane; j < N; j += 64) {
+            S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
+            S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();  // wave-private region: LDS is in order per wave
+        for (int ch = lane; ch < Dp; ch += 64) {
+            double EO, EN;
+            mh_lsf(P, S.gO, S.gN, ch, &EO, &EN);
+            S.G[ch] = EO;
+            sEN[ch] = EN;
+        }
+    };
+
+    bool ok = true;
+    for (int si = 0; si < F.n_sweeps; ++si) {
+        const uint32_t sweep = F.sweep0 + (uint32_t)si;
+        // Sweep start.  The 3 x 3 neighbourhood has completed the previous sweep: none of
+        // its workgroups still reads a G row of the ring half this sweep overwrites.
+        if (si > 0 && wave == 0 && lane < 9) {
+            const int ny = iy + lane / 3 - 1, nx = ix + lane % 3 - 1;
+            if (ny >= 0 && ny < F.n_sy && nx >= 0 && nx < F.n_sx)
+                ok = chain_wait(F.flag2 + ny * F.n_sx + nx, F.base + (unsigned)(si * F.K), F.err);
+        }
+        // The proposals of the whole sweep, one colour per thread: they depend on the
+        // spaxel's own parameters and its Philox stream only (lib/run.py:369-388).
+        for (int k2 = tid; k2 < F.K; k2 += NT) {
+            const int2 col = F.cols[k2];
+            const int y = chain_lattice_point(ylo, col.x, fh), x = chain_lattice_point(xlo, col.y, fw);
+            if (y >= F.py0 && y < F.py1 && x >= F.px0 && x < F.px1 && P.mask[y * P.W + x]) {
+                const long sp = (long)y * P.W + x;
+                const uint32_t gsp = (uint32_t)((y + P.gy0) * P.Wg + (x + P.gx0));
+                const double a = si ? snew[3 * k2 + 0] : P.params[sp * 3 + 0];
+                const double cc = si ? snew[3 * k2 + 1] : P.params[sp * 3 + 1];
+                const double w = si ? snew[3 * k2 + 2] : P.params[sp * 3 + 2];
+                sprop[k2] = mh_propose_from(P, a, cc, w, gsp, sweep);
+            }
+        }
+        if (__syncthreads_or(!ok)) return;  // a timed-out wait: *F.err is set, the host reports it
+        Geo cur = geometry(si, 0);
+        build_table(cur, 0, NT);
+        if (wave == 0) build_lines(cur, 0);
+        __syncthreads();
+
+        for (int k = 0; k < F.K; ++k) {
+            const unsigned E = F.base + (unsigned)(si * F.K + k) + 1u;
+            const int sp = cur.y * P.W + cur.x;
+            D3D_CHAIN_STAMP(0);
+            // ---- (1) the window into registers, as soon as the predecessors have stored it
+            int vox[UT];
+            double2 e[UT], v[UT];
+            const bool loads = has_window && cur.present && (cur.real || cur.have_pred);
+            if (streamer && cur.present && cur.have_pred) {
+                if (lane < 4)
+                    ok = chain_wait(F.flag1 + slot_of((lane & 2) ? cur.py1l : cur.py0l,
+                                                      (lane & 1) ? cur.px1l : cur.px0l),
+                                    E - 1u, F.err);
+                ok = __all(ok);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // keep the loads below the poll
+            }
+#pragma unroll
+            for (int i = 0; i < UT; ++i) {
+                const int pw = g + i * G;
+                const int p = cur.rev ? npos - 1 - pw : pw;
+                vox[i] = (loads && pw < npos) ? S.pos[2 * p] : -1;
+                e[i] = make_double2(0.0, 0.0);
+                v[i] = vu;
+                if (vox[i] >= 0) {
+                    const long idx = (long)vox[i] * Dp + 2 * zl;
+                    cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
+                    e[i] = cv.d;
+                    if (!UV) v[i] = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                }
+            }
+            D3D_CHAIN_STAMP(1);
+            // ---- (2) the predecessors' G rows (sc1 loads) into LDS
+            if (streamer && cur.present && cur.have_pred) {
+                if (lane < 4)
+                    ok = ok && chain_wait(F.flag2 + slot_of((lane & 2) ? cur.py1l : cur.py0l,
+                                                            (lane & 1) ? cur.px1l : cur.px0l),
+                                          E - 1u, F.err);
+                ok = __all(ok);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const double *Gp = F.G + ((size_t)cur.pring * F.K + cur.pk) * slots * Dp;
+                for (int i = tid; i < 4 * Dp; i += NS) {
+                    const int qd = i / Dp, z = i - qd * Dp;
+                    // (a lattice point outside the cube is no spaxel: no update, mh_ws_preds)
+                    const int sy = (qd & 2) ? cur.I.psy1[0] : cur.I.psy0[0];
+                    const int sx = (qd & 1) ? cur.I.psx1[0] : cur.I.psx0[0];
+                    double gv = 0.0;
+                    if (sy >= 0 && sx >= 0)
+                        gv = __longlong_as_double((long long)__hip_atomic_load(
+                            reinterpret_cast<const unsigned long long *>(
+                                Gp + (size_t)slot_of(sy, sx) * Dp + z),
+                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    S.gp[i] = gv;
+                }
+            }
+            D3D_CHAIN_STAMP(2);
+            if (__syncthreads_or(!ok)) return;  // B0: G rows staged
+            // ---- (3) apply the pending layer, store, accumulate -- from registers
+            if (has_window && cur.present) {
+                double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
+#pragma unroll
+                for (int i = 0; i < UT; ++i) {
+                    if (vox[i] < 0) continue;
+                    const int pw = g + i * G;
+                    const int p = cur.rev ? npos - 1 - pw : pw;
+                    const int code = cur.have_pred ? S.pos[2 * p + 1] : -1;
+                    if (code >= 0) {
+                        const double fp = S.fsf[code & 0xffff];
+                        const double2 gz = *reinterpret_cast<const double2 *>(
+                            S.gp + (size_t)(code >> 16) * Dp + 2 * zl);
+                        e[i].x = fma(fp, gz.x, e[i].x);
+                        e[i].y = fma(fp, gz.y, e[i].y);
+                        cv.d = e[i];
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            cv.i, err_rsrc, (int)(((long)vox[i] * Dp + 2 * zl) * 8), 0, 16);
+                    }
+                    const double f = S.fsf[p];
+                    D3D_ACCUM(e[i], v[i], f);
+                }
+                if (cur.real) {
+                    double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
+                    r[0] = sA.x;
+                    r[1] = sA.y;
+                    r[Dp] = sB.x;
+                    r[Dp + 1] = sB.y;
+                    r[2 * Dp] = sC.x;
+                    r[2 * Dp + 1] = sC.y;
+                }
+            }
+            __syncthreads();  // B1: group partial sums are in S.red
+            D3D_CHAIN_STAMP(3);
+            MHProposal q = {};
+            double EO = 0.0, EN = 0.0;
+            if (cur.real) {
+                q = sprop[k];
+                if (streamer) {
+                    if (tid < Dp) {
+                        EO = S.G[tid];
+                        EN = sEN[tid];
+                    }
+                    mh_channel_sums(P, S, q, tid, G, EO, EN, 0);
+                }
+            }
+            __syncthreads();  // B2: the wave sums are in S.sum
+            D3D_CHAIN_STAMP(4);
+            // ---- (4) the extra wavefront decides; meanwhile the streaming wavefronts drain
+            // their residual stores (flag1) and build the next colour's table and lines
+            const bool more = k + 1 < F.K;
+            Geo nxt = cur;
+            if (more) nxt = geometry(si, k + 1);
+            if (!streamer) {
+                if (cur.real) {
+                    const U2 u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
+                    mh_decide_wave(P, S, q, sp, sweep, NW, u_gibbs);
+                    if (lane == 0) {  // the state the next sweep's proposal starts from
+                        const double *verdict = S.sum + 8 * NW;
+                        const bool accept = verdict[0] != 0.0;
+                        snew[3 * k + 0] = verdict[1];
+                        snew[3 * k + 1] = accept ? q.pn[1] : q.c_old;
+                        snew[3 * k + 2] = accept ? q.pn[2] : q.w_old;
+                    }
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's sc1 stores
+                if (lane == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(&sctl[0], 1u, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (old == (unsigned)(NW - 1)) {  // the last wavefront to drain signals
+                        __hip_atomic_store(&sctl[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(F.flag1 + slot, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                if (more) {
+                    if (wave == 0 || NW == 1) build_lines(nxt, k + 1);
+                    if (NW > 1 && wave >= 1) build_table(nxt, 64, NS - 64);
+                    if (NW == 1) build_table(nxt, 0, NS);
+                }
+            }
+            __syncthreads();  // B3: verdict; next colour's table and lines
+            D3D_CHAIN_STAMP(5);
+            // ---- (5) publish the G row
+            if (tid < nstore * 64) {
+                if (cur.present && tid < Dp) {
+                    const double Gt = cur.real ? mh_update_coeff(P, S, q, tid, EO, EN, NW) : 0.0;
+                    double *dst = F.G + (((size_t)(si & 1) * F.K + k) * slots + slot) * Dp + tid;
+                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst),
+                                       (unsigned long long)__double_as_longlong(Gt), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    // the pending layer this launch leaves, where flush_pending and the next
+                    // launch look for it (in-cube lattice points only, as mh_ws_zero_row)
+                    if (!more && si == F.n_sweeps - 1 && cur.y >= 0 && cur.y < P.H && cur.x >= 0 &&
+                        cur.x < P.W)
+                        F.Gout[((long)(cur.y / fh) * P.slots_x + cur.x / fw) * Dp + tid] = Gt;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(&sctl[1], 1u, __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (old == (unsigned)(nstore - 1)) {
+                        __hip_atomic_store(&sctl[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(F.flag2 + slot, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            D3D_CHAIN_STAMP(6);
+            cur = nxt;
+        }
+    }
+}
+
+#ifdef D3D_EXPERIMENTS
 // ---- one launch per sweep: dataflow over the colour classes ----------------
 //
-// OPT-IN (D3D_MH_FLOW=1).  Measured on MI355X at 300x300x128 / 11x11: 54.9 us
+// EXPERIMENTS build only (make EXPERIMENTS=1, option mh_flow = 1).  Measured on MI355X at 300x300x128 / 11x11: 54.9 us
 // per colour against 48.4 us for one k_mh_ws launch per colour (uniform
 // variance: 49.0 vs 39.1) -- the chain colour k -> k+1 is serial per window, so
 // every microsecond of hand-off latency (ticket, flag poll, write-through drain)
@@ -2587,14 +3037,6 @@ struct MHFlow {
     int K, LY, LX, pb, items;
     unsigned epoch;
 };
-
-__device__ __forceinline__ int covering_lattice(int q, int c, int per, int hw) {
-    int m = (q - c) % per;
-    if (m < 0) m += per;
-    int s = q - m;
-    if (q - s > hw) s += per;
-    return s;
-}
 
 __device__ __forceinline__ bool flow_wait(const unsigned *addr, unsigned want, bool at_least,
                                           unsigned *err) {
@@ -2719,7 +3161,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_flow(MHArgs P, MHFlow F, uint32_
 //     B window waits for.
 // One kernel boundary less per colour pair; bit-identical to the per-colour launches
 // (same windows, same arithmetic; tests/test_gpu_parity.py, test_gpu_full_size.py).
-// OPT-IN (D3D_MH_PAIR=1).  Measured on MI355X at 300x300x128 / 11x11: 43.0 us per colour
+// EXPERIMENTS build only (option mh_pair = 1).  Measured on MI355X at 300x300x128 / 11x11: 43.0 us per colour
 // against 42.0 for one launch per colour.  The boundary it saves (an empty pair launch
 // costs 3.7 us) is paid back as dependency wait: all windows of colour A are resident at
 // once, share the HBM stream equally and therefore finish TOGETHER, so no B window can
@@ -2822,6 +3264,8 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     }
 }
 
+#endif  // D3D_EXPERIMENTS (k_mh_flow, k_mh_pair)
+
 // Replay of updates made by ANOTHER tile (multi-GPU spatial tiling): one
 // workgroup per record {ly, lx, a_old, c_old, w_old, a_new, c_new, w_new} with
 // (ly, lx) in this tile's local coordinates (possibly outside it).  Recomputes
@@ -2878,7 +3322,7 @@ __global__ __launch_bounds__(NT) void k_apply_updates(MHArgs P, const double *__
 
 // Records of the last update of the listed spaxels, for a neighbour tile:
 // {global y, global x, a_old, c_old, w_old, a_new, c_new, w_new}.
-__global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
+static __global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
                                  double *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -2898,7 +3342,7 @@ __global__ void k_gather_updates(MHArgs P, const int *__restrict__ idx, int n,
 // (spaxel i, sweep 0).  wave_mode = 0: one thread per draw (scalar form);
 // wave_mode = 1: one wavefront per draw, every lane the same arguments -- the
 // form mh_finish runs (the two CDFs side by side in the wavefront's halves).
-__global__ __launch_bounds__(256) void k_rtnorm(long n, double lo, double hi, double mu,
+static __global__ __launch_bounds__(256) void k_rtnorm(long n, double lo, double hi, double mu,
                                                  double sigma, uint64_t seed, int wave_mode,
                                                  double *__restrict__ out) {
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2949,7 +3393,7 @@ __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
 // Halo exchange of the tiled chain: the cells (all E values per spaxel: E = Dp for
 // a cube, 3 for the parameter map) of the rectangle [y0,y1) x [x0,x1) of a (H,W,E)
 // array to / from a packed buffer.  A row of the rectangle is one contiguous run.
-__global__ __launch_bounds__(256) void k_rect_copy(double *__restrict__ arr, int W, int E, int y0,
+static __global__ __launch_bounds__(256) void k_rect_copy(double *__restrict__ arr, int W, int E, int y0,
                                                     int x0, int ny, int nx,
                                                     double *__restrict__ packed, int unpack) {
     const long run = (long)nx * E;

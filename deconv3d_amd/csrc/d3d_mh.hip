@@ -1,0 +1,402 @@
+// Launchers of the MH-within-Gibbs kernels (d3d_kernels.h).  gfx950 only.
+#include "d3d_ctx.h"
+
+namespace d3dh {
+
+using namespace d3d;
+
+void pend_clear(d3d_ctx *c) {
+    c->lay_n = 0;
+    c->pend_part = -1;
+}
+
+// a G buffer that holds no pending layer
+int pend_free_buf(const d3d_ctx *c) {
+    for (int b = 0; b < 4; ++b) {
+        bool used = false;
+        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
+        if (!used) return b;
+    }
+    return 0;  // unreachable: at most 3 layers
+}
+
+void pend_push(d3d_ctx *c, int cy, int cx, int g) {
+    c->lay_cy[c->lay_n] = cy;
+    c->lay_cx[c->lay_n] = cx;
+    c->lay_g[c->lay_n] = g;
+    ++c->lay_n;
+}
+
+void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
+    P.D = c->D;
+    P.Dp = c->Dp;
+    P.HL = c->HL;
+    P.H = c->H;
+    P.W = c->W;
+    P.fh = c->fh;
+    P.fw = c->fw;
+    P.N = c->N;
+    P.ntaps = c->ntaps;
+    P.npos = c->fh * c->fw;
+    P.err = c->slot[D3D_SLOT_ERR];
+    P.ivar = c->slot[D3D_SLOT_IVAR];
+    P.ivar_uniform = c->ivar_uniform;
+    P.params = c->params;
+    P.prev = c->prev;
+    P.fsf = c->fsf;
+    P.shift = c->lsf_shift;
+    P.weight = c->lsf_weight;
+    P.dlog = c->dlog;
+    P.accepted = c->accepted;
+    P.spx = c->spx;
+    P.rev = 0;
+    for (int k = 0; k < 3; ++k) {
+        P.min_b[k] = c->min_b[k];
+        P.max_b[k] = c->max_b[k];
+        P.amp[k] = c->amp[k];
+    }
+    P.ra = c->ra;
+    P.seed = c->seed;
+    P.gy0 = c->gy0;
+    P.gx0 = c->gx0;
+    P.Wg = c->Wg;
+    // the domain of the part whose layers are pending (the whole cube when none are)
+    if (c->pend_part >= 0 && c->pend_part < (int)c->parts.size()) {
+        const d3d_ctx::Part &pt = c->parts[c->pend_part];
+        P.dy0 = pt.dy0;
+        P.dy1 = pt.dy1;
+        P.dx0 = pt.dx0;
+        P.dx1 = pt.dx1;
+    } else {
+        P.dy0 = 0;
+        P.dy1 = c->H;
+        P.dx0 = 0;
+        P.dx1 = c->W;
+    }
+    P.mask = c->mask;
+    P.n_lay = c->lay_n;
+    P.write_back = 1;
+    for (int j = 0; j < 3; ++j) {
+        const bool live = j < c->lay_n;
+        P.lay_cy[j] = live ? c->lay_cy[j] : -1;
+        P.lay_cx[j] = live ? c->lay_cx[j] : -1;
+        P.lay_G[j] = c->gbuf[live ? c->lay_g[j] : 0];
+    }
+    P.Gcur = c->gbuf[pend_free_buf(c)];
+    // the kernels that keep one pending layer (k_mh_defer, k_mh_flow) see the newest
+    const int last = c->lay_n - 1;
+    P.Gprev = c->gbuf[last >= 0 ? c->lay_g[last] : 0];
+    P.prev_cy = last >= 0 ? c->lay_cy[last] : -1;
+    P.prev_cx = last >= 0 ? c->lay_cx[last] : -1;
+    P.slots_x = c->slots_x;
+    P.ext_idx = nullptr;
+    P.ext_in = nullptr;
+    P.ext_lines = nullptr;
+    P.ext_out = nullptr;
+    P.ext_gibbs = 1;
+    P.probe = 0;
+    P.probe_sp = 0;
+    P.probe_p[0] = P.probe_p[1] = P.probe_p[2] = 0.0;
+    P.probe_out = c->scal;
+#ifdef D3D_EXPERIMENTS
+    P.stamp = nullptr;
+#endif
+}
+
+template <int NT, int MAXIT>
+int launch_mh_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh<NT, MAXIT>), dim3(grid), dim3(NT), lds, c->stream,
+                       P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NT>
+int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    switch (c->mh_maxit) {
+        case 4: return launch_mh_t<NT, 4>(c, P, grid, sweep);
+        case 8: return launch_mh_t<NT, 8>(c, P, grid, sweep);
+        case 16: return launch_mh_t<NT, 16>(c, P, grid, sweep);
+        case 32: return launch_mh_t<NT, 32>(c, P, grid, sweep);
+        default: return launch_mh_t<NT, 0>(c, P, grid, sweep);
+    }
+}
+
+int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    switch (c->mh_nt) {
+        case 128: return launch_mh_nt<128>(c, P, grid, sweep);
+        case 256: return launch_mh_nt<256>(c, P, grid, sweep);
+        case 512: return launch_mh_nt<512>(c, P, grid, sweep);
+        default: return launch_mh_nt<1024>(c, P, grid, sweep);
+    }
+}
+
+template <int NT>
+int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_lds_doubles(NT, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_defer<NT>), dim3(grid), dim3(NT), lds, c->stream,
+                       P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <bool UV, int U, int M, int K, bool NTV = false, int NS = 256>
+int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
+    // (the number of pending layers as a template constant: see k_mh_ws)
+    switch (P.n_lay <= M ? P.n_lay : -1) {
+        case 0:
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0, NTV>), dim3(grid),
+                               dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 1:
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1, NTV>), dim3(grid),
+                               dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 2:
+            if constexpr (M >= 2)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2, NTV>), dim3(grid),
+                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        case 3:
+            if constexpr (M >= 3)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3, NTV>), dim3(grid),
+                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            break;
+        default:
+            return fail(D3D_ERR_STATE, "internal: %d pending layers for a %d-layer kernel", P.n_lay, M);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// A launch that does not fill the chip (fewer workgroups than 2 per CU) is
+// latency-bound: four window positions in flight per wavefront instead of one.
+// The kernels for several pending layers need more LDS; with one layer
+// configured the lean variant runs.  The pending G rows of a layer (4*Dp values)
+// are staged in 2 registers per thread up to Dp = 160, in 4 beyond.
+// layers: the pending layers the PART being updated uses (Part::layers) -- the kernel
+// family follows the part, not the context: a small part and a chip-filling part of one
+// context take different ones.
+template <bool UV>
+int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+    // (the uniform-variance variant also gains from the deeper queue at full size:
+    // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
+    const bool small = UV || grid < (unsigned)c->flow_grid / 2;
+    // (with several layers most launches only read: two positions in flight pay at
+    // full size, 43.3 -> 42.6 us per colour; chosen per kind of launch instead -- four for
+    // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
+    // against 40.8 with two for both.  Round 2, for launches that do not fill the
+    // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
+    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); fifteen
+    // streaming wavefronts per window: see the 960-thread form below)
+    // (1/variance with the non-temporal hint when the context's working set exceeds the
+    // Infinity Cache: mh_load_ivar; only the chip-filling launches have the variant)
+    if constexpr (!UV) {
+        if (c->mh_nt_ivar && !small) {
+            if (layers >= 3) return launch_mh_ws_um<UV, 2, 3, 2, true>(c, P, grid, sweep);
+            if (layers == 2) {
+                if (c->Dp > 160) return launch_mh_ws_um<UV, 2, 2, 4, true>(c, P, grid, sweep);
+                return launch_mh_ws_um<UV, 2, 2, 2, true>(c, P, grid, sweep);
+            }
+            return launch_mh_ws_um<UV, 1, 1, 4, true>(c, P, grid, sweep);
+        }
+    }
+    if (layers >= 3) {  // Dp <= 160
+        if (small) return launch_mh_ws_um<UV, 4, 3, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 3, 2>(c, P, grid, sweep);
+    }
+    if (layers == 2) {
+        if (c->Dp > 160) {
+            if (small) return launch_mh_ws_um<UV, 4, 2, 4>(c, P, grid, sweep);
+            return launch_mh_ws_um<UV, 2, 2, 4>(c, P, grid, sweep);
+        }
+        if (small) return launch_mh_ws_um<UV, 4, 2, 2>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 2, 2, 2>(c, P, grid, sweep);
+    }
+    // The small launches of a PARTITIONED context (tiles, d3d_set_parts) at 128 channels: a
+    // launch of at most one workgroup per CU is bound by how fast ONE workgroup gets through
+    // its window (121 positions through four wavefronts, ~1 us per round trip), so fifteen
+    // streaming wavefronts instead of four (k_mh_ws<960>, ONE position in flight per
+    // wavefront: 3.52 ms against 3.61 with two and 3.77 with four): an 8x1 rank of
+    // 300x300x128 4.18 -> 3.52 ms per sweep.  (What then bounds such a launch, by the phase
+    // stamps: setup 2.3 us, the prepare wavefront's proposal -> line -> LSF chain 6.4, the
+    // decision tail 4.5, the kernel boundary 2.4; a second prepare wavefront for the
+    // current line gained 1.5 %: not kept.)  Another grouping of the window sums than the 256-thread form
+    // (results agree to rounding, not bit for bit), hence only where nothing is compared bit for
+    // bit with another scheme: a given part always takes the same form, so a tiled chain and
+    // the single context given the same parts still agree to the last bit.  Shallow cubes lose
+    // (32 channels: 9.9 -> 12.2 us per launch).  D3D_MH_WIDE=0: off.
+    if (small && c->mh_wide && (c->tiled || !c->part_rects.empty()) && c->Dp == 128 &&
+        grid <= (unsigned)c->flow_grid / 4)
+        return launch_mh_ws_um<UV, 1, 1, 1, false, 960>(c, P, grid, sweep);
+    if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
+    return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
+}
+
+#ifdef D3D_EXPERIMENTS
+// One sweep in one launch (k_mh_flow).  P carries the pending colour of the
+// previous sweep; afterwards the last active colour of this one is pending.
+template <bool UV>
+int launch_mh_flow_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHFlow &F, uint32_t sweep) {
+    constexpr int NS = 256;
+    size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos) * sizeof(double);
+    lds += 16;  // the ticket
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_flow<NS, UV>), dim3((unsigned)c->flow_items),
+                       dim3(NS + 64), lds, c->stream, P, F, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_flow(d3d_ctx *c, uint32_t sweep) {
+    HIP_TRY(hipMemsetAsync(c->flow_state, 0, c->flow_state_bytes, c->stream));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
+    d3d::MHFlow F;
+    F.ent = c->flow_ent;
+    F.col = c->flow_col;
+    F.lat = c->flow_lat;
+    F.ctl = c->flow_state;
+    F.cnt = c->flow_state + 4;
+    F.done = c->flow_state + 4 + c->flow_cap_K;
+    F.err = c->flow_err;
+    for (int b = 0; b < 3; ++b) F.gbuf[b] = c->gbuf[b];
+    F.K = c->flow_K;
+    F.LY = c->flow_LY;
+    F.LX = c->flow_LX;
+    F.pb = c->lay_n ? c->lay_g[c->lay_n - 1] : 0;  // (one layer at most: launch_mh_flow's caller)
+    F.items = c->flow_items;
+    F.epoch = 1;
+    const int rc = (c->ivar_is_uniform && c->uniform_fast_path)
+                       ? launch_mh_flow_t<true>(c, P, F, sweep)
+                       : launch_mh_flow_t<false>(c, P, F, sweep);
+    if (rc) return rc;
+    pend_clear(c);
+    pend_push(c, c->flow_last_cy, c->flow_last_cx, (F.pb + c->flow_K) % 3);
+    return 0;
+}
+
+// Colours ka (N: one layer pending, nothing written) and ka+1 (W) of the active-colour
+// list in ONE launch (k_mh_pair).  P carries the one pending layer.
+template <bool UV, int U, int K>
+int launch_mh_pair_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHPair &F, uint32_t sweep) {
+    constexpr int NS = 256;
+    const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, 2) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_pair<NS, UV, U, K>), dim3((unsigned)(F.n_a + F.n_b)),
+                       dim3(NS + 64), lds, c->stream, P, F, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    P.rev = c->mh_zigzag;  // zig-zag enabled: the kernel derives each item's direction
+    d3d::MHPair F;
+    F.ent = c->flow_ent;
+    F.lat = c->flow_lat;
+    F.ctl = c->pair_state;
+    F.done = c->pair_state + 4;
+    F.err = c->flow_err;
+    F.first_a = c->flow_first[ka];
+    F.n_a = c->flow_first[ka + 1] - c->flow_first[ka];
+    F.first_b = c->flow_first[ka + 1];
+    F.n_b = c->flow_first[ka + 2] - c->flow_first[ka + 1];
+    F.ka = ka;
+    F.a_cy = c->flow_colour[ka] / c->fw;
+    F.a_cx = c->flow_colour[ka] % c->fw;
+    F.LY = c->flow_LY;
+    F.LX = c->flow_LX;
+    F.ticket_base = c->pair_tickets;
+    F.epoch = ++c->pair_epoch;
+    const int ga = pend_free_buf(c);
+    int gb = 0;
+    for (int b = 0; b < 4; ++b) {
+        bool used = b == ga;
+        for (int j = 0; j < c->lay_n; ++j) used = used || c->lay_g[j] == b;
+        if (!used) gb = b;
+    }
+    F.G_a = c->gbuf[ga];
+    F.G_b = c->gbuf[gb];
+    c->pair_tickets += (unsigned)(F.n_a + F.n_b);
+    const bool uv = c->ivar_is_uniform && c->uniform_fast_path;
+    int rc;
+    if (c->Dp > 160)
+        rc = uv ? launch_mh_pair_t<true, 4, 4>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 4>(c, P, F, sweep);
+    else
+        rc = uv ? launch_mh_pair_t<true, 4, 2>(c, P, F, sweep) : launch_mh_pair_t<false, 2, 2>(c, P, F, sweep);
+    if (rc) return rc;
+    // afterwards colour B's updates are the only pending layer (local residues == colour
+    // indices: an unpartitioned, untiled context)
+    c->lay_n = 0;
+    pend_push(c, c->flow_colour[ka + 1] / c->fw, c->flow_colour[ka + 1] % c->fw, gb);
+    c->pend_part = 0;
+    return 0;
+}
+#endif  // D3D_EXPERIMENTS
+
+int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+    // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
+    // tail, so D <= 256) + one prepare wavefront
+    if (c->mh_defer == 1 && c->Dp <= 256) {
+        if (c->ivar_is_uniform && c->uniform_fast_path)
+            return launch_mh_ws<true>(c, P, grid, sweep, layers);
+        return launch_mh_ws<false>(c, P, grid, sweep, layers);
+    }
+    switch (c->mh_nt) {
+        case 128: return launch_mh_defer_nt<128>(c, P, grid, sweep);
+        case 256: return launch_mh_defer_nt<256>(c, P, grid, sweep);
+        case 512: return launch_mh_defer_nt<512>(c, P, grid, sweep);
+        default: return launch_mh_defer_nt<1024>(c, P, grid, sweep);
+    }
+}
+
+// Write the pending (deferred) residual updates into SLOT_ERR.
+int flush_pending(d3d_ctx *c) {
+    if (c->lay_n == 0) return 0;
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const int NT = 256;
+    const int S = NT / c->HL > 0 ? NT / c->HL : 1;
+    const long cells = (long)(P.dy1 - P.dy0) * (P.dx1 - P.dx0);  // of the pending part's domain
+    if (cells > 0) {
+        if (c->HL <= 256) {
+            const unsigned grid = (unsigned)((cells + S - 1) / S);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
+                               c->stream, P);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)cells),
+                               dim3(1024), 0, c->stream, P);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    pend_clear(c);
+    return 0;
+}
+
+
+int launch_apply_updates(d3d_ctx *c, const d3d::MHArgs &P, const double *rec, int n) {
+    const size_t lds = (size_t)(2 * c->N + c->Dp) * sizeof(double);
+    if (c->HL <= 256) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<256>), dim3((unsigned)n), dim3(256),
+                           lds, c->stream, P, rec, n);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_apply_updates<1024>), dim3((unsigned)n),
+                           dim3(1024), lds, c->stream, P, rec, n);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma, uint64_t seed,
+                  int wave_mode, double *buf) {
+    const long threads = wave_mode ? n * 64 : n;
+    hipLaunchKernelGGL(d3d::k_rtnorm, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                       n, lo, hi, mu, sigma, seed, wave_mode, buf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace d3dh

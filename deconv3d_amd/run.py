@@ -62,8 +62,8 @@ class Run:
     ``min_acceptance_rate``; plus ``seed``, ``device``, ``refresh_every``,
     ``sweeps_per_call``, ``checkpoint`` (file prefix written every
     ``write_every`` iterations) and ``resume_state`` (the ``<prefix>_state.npz``
-    of a checkpoint: the sweep numbering, the accepted count and hence the
-    random-number streams continue where the checkpointed run stopped; pass the
+    of a checkpoint: the sweep numbering -- hence the random-number streams -- and the
+    accepted count of the stopping rule continue where the checkpointed run stopped; pass the
     checkpoint's ``<prefix>_parameters.npy`` as ``initial_parameters``), and
     ``chain_file`` (file prefix: chain and likelihoods live in memory-mapped
     ``<prefix>_chain.npy`` / ``<prefix>_likelihoods.npy`` instead of RAM, written as the
@@ -270,7 +270,11 @@ class Run:
                 self.logger.warning("resume_state was written with seed %d, this run uses %d"
                                     % (int(state["seed"]), self.seed))
             self.sweep_origin = int(state["sweep_origin"]) + int(state["iteration"]) - 1
-            resumed_accepted = (int(state["accepted_count"]), int(state["iteration"]))
+            # totals over every earlier segment (older checkpoints hold one segment's)
+            files = getattr(state, "files", state)
+            resumed_accepted = (
+                int(state["total_accepted"] if "total_accepted" in files else state["accepted_count"]),
+                int(state["total_iterations"] if "total_iterations" in files else state["iteration"]))
             if host_chain is None:
                 self.engine.set_sweep_origin(self.sweep_origin)
             else:
@@ -283,7 +287,12 @@ class Run:
         cur_iteration = 1
         cur_acceptance_rate = 0.
         accepted_count = spaxels_count             # first iteration counts as accepted
-        self._resumed_from = resumed_accepted      # (accepted, iterations) of earlier segments
+        # (accepted, iterations) of earlier segments: the running acceptance rate of the
+        # stopping rule (lib/run.py:344-359) is that of the WHOLE chain.  This segment's
+        # iteration 1 is the resumed state itself, already counted there.
+        self._resumed_from = resumed_accepted
+        self._acc_base = resumed_accepted[0] - spaxels_count if resumed_accepted else 0
+        self._it_base = resumed_accepted[1] - 1 if resumed_accepted else 0
         # the reference re-evaluates the stopping rule (and logs) every sweep
         # (lib/run.py:344-364): one sweep per device call whenever the rule is
         # armed, so that the run stops exactly where the reference would; with
@@ -295,9 +304,9 @@ class Run:
         self.iterations_done = 1
         while cur_iteration < max_iterations and \
                 (cur_acceptance_rate > min_acceptance_rate or cur_acceptance_rate == 0.):
-            max_accepted_count = spaxels_count * cur_iteration
+            max_accepted_count = spaxels_count * (cur_iteration + self._it_base)
             if max_accepted_count > 0:
-                cur_acceptance_rate = float(accepted_count) / float(max_accepted_count)
+                cur_acceptance_rate = float(accepted_count + self._acc_base) / float(max_accepted_count)
             n = min(sweeps_per_call, max_iterations - cur_iteration)
             self.logger.info("Iteration #%d / %d, %2.0f%%" %
                              (cur_iteration + 1, max_iterations, 100 * cur_acceptance_rate))
@@ -319,7 +328,8 @@ class Run:
                 self.iterations_done = cur_iteration
                 self._write_checkpoint(checkpoint, cur_iteration, accepted_count)
         self.iterations_done = cur_iteration
-        self.acceptance_rate = float(accepted_count) / float(max(spaxels_count * cur_iteration, 1))
+        self.acceptance_rate = float(accepted_count + self._acc_base) / \
+            float(max(spaxels_count * (cur_iteration + self._it_base), 1))
         if chain_file is not None:
             n_valid = (cur_iteration - 1) // self.keep_one_in + 1
             self.chain[n_valid:] = np.nan
@@ -354,14 +364,23 @@ class Run:
     def _write_checkpoint(self, name, iteration, accepted_count):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
         lib/run.py:790-797), `<name>_chain.npy` (slots written so far) and
-        `<name>_state.npz` (iteration, seed, accepted count: `resume_state=`)."""
+        `<name>_state.npz` (iteration, seed, accepted count: `resume_state=`).
+        A memory-mapped chain (`chain_file=`) is flushed where it lives instead of
+        copied: the checkpoint then names its files, and `chain_file == checkpoint`
+        cannot rewrite the file under the open mapping."""
         np.savez("%s_state.npz" % name, iteration=iteration, seed=self.seed,
                  accepted_count=accepted_count, sweep_origin=self.sweep_origin,
-                 keep_one_in=self.keep_one_in)
+                 keep_one_in=self.keep_one_in,
+                 total_accepted=accepted_count + self._acc_base,
+                 total_iterations=iteration + self._it_base,
+                 chain_file="" if self._chain_file is None else str(self._chain_file))
         np.save("%s_parameters.npy" % name, self._host_chain.params if self._host_model
                 else self.engine.get_params())
         n_valid = (iteration - 1) // self.keep_one_in + 1
-        np.save("%s_chain.npy" % name, self.chain[:n_valid])
+        if self._chain_file is not None:
+            self.chain.flush()
+        else:
+            np.save("%s_chain.npy" % name, self.chain[:n_valid])
         self.logger.info("checkpoint at iteration %d (%d accepted) -> %s_*.npy"
                          % (iteration, accepted_count, name))
 

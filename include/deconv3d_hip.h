@@ -82,6 +82,26 @@ int d3d_sync(d3d_ctx *ctx);
 /* HIP-event stopwatch on the ctx stream (for bench.py's roofline leg). */
 int d3d_timer_start(d3d_ctx *ctx);
 int d3d_timer_stop(d3d_ctx *ctx, double *elapsed_ms);
+/* Per-context options: which kernel family / geometry a ctx uses where the library
+ * has more than one (the reference has no counterpart: numpy picks nothing,
+ * lib/run.py:3-31 is its whole import list).  Every default is the measured best and
+ * every choice gives the same chain (bit for bit unless DESIGN.md says "to rounding"),
+ * so none is needed in normal use; they exist for the bit-identity tests and for A/B
+ * measurements.  An option belongs to ONE ctx: two contexts of a process may differ.
+ * The environment variable D3D_<KEY> (upper case) only supplies a NEW ctx's default.
+ * Changing an option flushes pending residual updates and re-derives what depends
+ * on it (work lists, tap analysis), so it may be called at any time between calls.
+ * Keys: mh_defer 0|1|2, mh_layers 0(auto)|1|2|3, mh_chain -1(auto)|0|1,
+ * mh_wide, mh_zigzag, mh_nt_ivar -1(auto)|0|1, mh_nt, mh_maxit, uniform_ivar, conv_rows,
+ * conv_hy, spatial_sep, sep_fuse, spatial_mode, march_hy, zmajor, zmajor_hy,
+ * spectral_dense, spatial_nt, xcd_remap, alt_dir, stagger; a build with
+ * `make EXPERIMENTS=1` adds mh_flow, mh_pair, spectral_shfl, fuse_lsf, march_pf,
+ * march_one, march_stamp.  Unknown key or value out of range: D3D_ERR_INVALID. */
+int d3d_ctx_set_option(d3d_ctx *ctx, const char *key, long value);
+int d3d_ctx_get_option(d3d_ctx *ctx, const char *key, long *value);
+/* 1 when the library was built with `make EXPERIMENTS=1` (the measured-but-not-faster
+ * kernel variants of DESIGN.md section 3 are present), else 0. */
+int d3d_has_experiments(void);
 
 /* ---- inputs ------------------------------------------------------------ */
 
@@ -193,14 +213,15 @@ int d3d_get_dlog(d3d_ctx *ctx, double *out_hw);
  * reference's default when Run gets variance=None (lib/run.py:171-178 builds a
  * constant cube from median_clip) -- so that d3d_mh_sweeps streams the residual
  * only (16 instead of 24 bytes per window voxel; results are bit-identical to
- * the general kernel).  Environment D3D_UNIFORM_IVAR=0 turns the variant off. */
+ * the general kernel).  Option uniform_ivar = 0 turns the variant off. */
 int d3d_variance_is_uniform(d3d_ctx *ctx, int *out);
 /* *out = number of colours whose residual updates d3d_mh_sweeps keeps pending as
  * (colour, coefficient rows) layers before it writes the residual back: 2 by
  * default (the residual is stored every second colour: writing it costs about
  * twice what reading it does on MI355X), 1 for cubes whose colour launches do not
  * fill the chip or whose depth exceeds 256, 0 when updates are written at once (tiled contexts).  The chain
- * is bit-identical for every value.  Environment D3D_MH_LAYERS=1|2|3. */
+ * is bit-identical for every value.  Option mh_layers = 1|2|3 forces a depth; a
+ * partitioned ctx reports the most layers any of its parts uses. */
 int d3d_mh_layers(d3d_ctx *ctx, int *out);
 
 /* ---- spatial tiling (one chain over several GPUs) --------- */

@@ -3,12 +3,10 @@ k_conv_rows (csrc/d3d_conv.h): the one-pass LSF (x) FSF convolution for 128-chan
 cubes and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
 register rings + LSF epilogue -- against the oracle's restatement of
 lib/convolution.py:89-120 and lib/run.py:1027-1029, and against the two-pass
-kernels it replaces (D3D_CONV_ROWS=0).  Shapes chosen to hit every border case of
+kernels it replaces (option conv_rows = 0).  Shapes chosen to hit every border case of
 the kernel's geometry: widths that are not a multiple of the 15 columns a workgroup
 owns, strips of unequal height, fewer rows than the FSF, single columns.
 """
-import os
-
 import numpy as np
 import pytest
 
@@ -19,19 +17,9 @@ pytestmark = pytest.mark.gpu
 
 
 def engine(shape, fsf, lsf, conv_rows=True, hy=None):
-    old = {k: os.environ.get(k) for k in ("D3D_CONV_ROWS", "D3D_CONV_HY")}
-    os.environ["D3D_CONV_ROWS"] = "1" if conv_rows else "0"
-    if hy is not None:
-        os.environ["D3D_CONV_HY"] = str(hy)
-    try:
-        eng = _lib.Engine(shape, fsf.shape)
-        eng.set_taps(fsf, lsf)          # the environment is read here
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    eng = _lib.Engine(shape, fsf.shape, options={"conv_rows": 1 if conv_rows else 0,
+                                                 "conv_hy": hy or 0})
+    eng.set_taps(fsf, lsf)
     return eng
 
 

@@ -178,26 +178,25 @@ def test_refresh_cadence_inside_mh_sweeps():
     assert np.max(np.abs(outs[0][1] - outs[1][1])) <= 1e-10 * np.max(np.abs(outs[0][1]))
 
 
-def test_pending_layer_policy(monkeypatch):
+def test_pending_layer_policy():
     """d3d_mh_layers: small cubes (colour launches that do not fill the chip) write
-    the residual back every colour, D3D_MH_LAYERS forces a depth, depths beyond
+    the residual back every colour, option mh_layers forces a depth, depths beyond
     160 / 256 channels cap it at 2 / 1, tiled contexts write at once."""
     fsf = O.gaussian_fsf_image(1.6)
 
-    def layers(D, env=None):
-        monkeypatch.delenv("D3D_MH_LAYERS", raising=False)
-        if env is not None:
-            monkeypatch.setenv("D3D_MH_LAYERS", env)
+    def layers(D, forced=None):
         H, W = 6, 7
         data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, None, seed=1)
         with _lib.Engine((D, H, W), fsf.shape) as eng:
             eng.set_taps(fsf, None)
             eng.set_data(data, var, mask=mask)
+            if forced is not None:     # after the data: the work lists are rebuilt
+                eng.set_option("mh_layers", forced)
             return eng.mh_layers()
 
     assert layers(64) == 1
-    assert layers(64, "2") == 2
-    assert layers(64, "3") == 3
-    assert layers(200, "3") == 2
-    assert layers(300, "3") == 1
+    assert layers(64, 2) == 2
+    assert layers(64, 3) == 3
+    assert layers(200, 3) == 2
+    assert layers(300, 3) == 1
 

@@ -1,10 +1,11 @@
 """
-Full-size (BASELINE config 3: 300x300x128, Moffat 11x11, 17-tap LSF) GPU tests
-through size-independent properties -- the oracle would need hours here:
-linearity and flux conservation of the separable convolution, agreement of its
-two device paths, consistency of the carried residual with a from-scratch one
-(lib/run.py:521-534), reproducibility of the chain under a seed, and agreement
-of a sub-region with the oracle.
+Full-size (BASELINE config 3: 300x300x128, Moffat 11x11, 17-tap LSF) GPU tests:
+size-independent properties (linearity and flux conservation of the separable
+convolution, agreement of its two device paths, consistency of the carried residual
+with a from-scratch one, lib/run.py:521-534, reproducibility of the chain under a
+seed, a sub-region of the forward model against the oracle) -- and, in
+tests/test_gpu_full_size_oracle.py, whole sweeps update by update against the oracle
+(about 20 s of oracle per 90 000-update sweep).
 """
 import numpy as np
 import pytest
@@ -97,25 +98,20 @@ def test_chain_reproducible_and_residual_consistent(problem):
 
 
 @pytest.mark.parametrize("uniform", [False, True])
-def test_sweep_dataflow_kernel_equals_per_colour_launches(monkeypatch, problem, uniform):
-    """k_mh_flow (one launch per sweep; windows wait for the flags of the <= 4
-    windows of the previous colour they intersect, sc1 hand-off across the XCDs)
-    against k_mh_ws (a kernel boundary after every colour) with the residual
-    written back every colour, every second and every third one: 270 000
-    updates, chains, residuals and delta maps bit-identical.  A stale line anywhere in a window
-    would show up here."""
+def test_pending_layer_depths_are_bit_identical_at_full_size(problem, uniform):
+    """k_mh_ws (a kernel boundary after every colour) with the residual written back every
+    colour, every second and every third one -- and, in a `make EXPERIMENTS=1` build,
+    k_mh_flow (one launch per sweep, sc1 hand-off across the XCDs) and k_mh_pair (two colour
+    classes per launch): 270 000 updates, chains, residuals and delta maps bit-identical.
+    A stale line anywhere in a window would show up here."""
     var = problem["var"] if uniform else problem["var"] * (
         0.75 + 0.5 * np.random.default_rng(5).random(problem["var"].shape))
     outs = []
-    # (D3D_MH_PAIR=1: two colour classes per launch, k_mh_pair, G rows handed over inside
-    # the launch)
-    for env in ({"D3D_MH_FLOW": "1"}, {"D3D_MH_LAYERS": "1"}, {"D3D_MH_LAYERS": "2"},
-                {"D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "1"}, {"D3D_MH_LAYERS": "3"}):
-        for k in ("D3D_MH_FLOW", "D3D_MH_DEFER", "D3D_MH_LAYERS", "D3D_MH_PAIR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with _lib.Engine((D, H, W), problem["fsf"].shape) as eng:
+    variants = [{"mh_layers": 1}, {"mh_layers": 2}, {"mh_layers": 3}]
+    if _lib.has_experiments():
+        variants += [{"mh_flow": 1}, {"mh_layers": 2, "mh_pair": 1}]
+    for opts in variants:
+        with _lib.Engine((D, H, W), problem["fsf"].shape, options=opts) as eng:
             eng.set_taps(problem["fsf"], problem["lsf"])
             eng.set_data(problem["data"], var)
             assert eng.variance_is_uniform() == uniform

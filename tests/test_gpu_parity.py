@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 CUBE_RTOL = 1e-12
 
 
-def engine_for(case):
+def engine_for(case, options=None):
     from deconv3d_amd import _lib
     D, H, W = case["D"], case["H"], case["W"]
-    eng = _lib.Engine((D, H, W), case["fsf"].shape)
+    eng = _lib.Engine((D, H, W), case["fsf"].shape, options=options)
     eng.set_taps(case["fsf"], case["lsf"])
     eng.set_data(case["data"], case["var"], mask=case["mask"])
     return eng
@@ -69,10 +69,10 @@ def test_convolve_arbitrary_cube(name):
 
 @pytest.mark.parametrize("kind", ["gaussian", "elliptical", "outer product of two ramps"])
 @pytest.mark.parametrize("shape", [(128, 40, 37), (30, 21, 50)])
-def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
+def test_outer_product_fsf_uses_the_separable_pass(kind, shape):
     """An FSF that is u v^T to rounding (every Gaussian with pa = 0) runs the
     spatial pass as 2*FS taps (k_spatial_sep).  Against the oracle's 2-D sum and
-    against the device's own 2-D kernel (D3D_SPATIAL_SEP=0): rounding only."""
+    against the device's own 2-D kernel (option spatial_sep = 0): rounding only."""
     from deconv3d_amd import _lib
     from deconv3d_amd.spread_functions import gaussian_image
     rng = np.random.default_rng(3)
@@ -91,10 +91,8 @@ def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
     # separable with the LSF in the same pass (power-of-two depths), separable
     # after the streaming LSF pass, 2-D kernel; each also through the forward
     # model, whose lines are already LSF-convolved (never the one-pass kernel)
-    for sep, fuse in (("1", "1"), ("1", "0"), ("0", "0")):
-        monkeypatch.setenv("D3D_SPATIAL_SEP", sep)
-        monkeypatch.setenv("D3D_SEP_FUSE", fuse)
-        with _lib.Engine(shape, fsf.shape) as eng:
+    for sep, fuse in ((1, 1), (1, 0), (0, 0)):
+        with _lib.Engine(shape, fsf.shape, options={"spatial_sep": sep, "sep_fuse": fuse}) as eng:
             eng.set_taps(fsf, lsf)
             eng.upload_slot(_lib.SLOT_TMP0, cube)
             eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
@@ -112,20 +110,21 @@ def test_outer_product_fsf_uses_the_separable_pass(monkeypatch, kind, shape):
         assert not np.array_equal(outs[0], outs[2])  # and the one-pass form too
 
 
-def test_spectral_pass_by_wavefront_shuffles_is_bit_identical(monkeypatch):
-    """D3D_SPECTRAL_SHFL=1: the dense LSF pass exchanges neighbouring channels
+def test_spectral_pass_by_wavefront_shuffles_is_bit_identical():
+    """Option spectral_shfl = 1 (EXPERIMENTS build): the dense LSF pass exchanges neighbouring channels
     with wavefront shuffles instead of the wave-private LDS window (depth 128: one
     spectrum per wavefront).  Same taps, same order: same bits."""
     from deconv3d_amd import _lib
+    if not _lib.has_experiments():
+        pytest.skip("k_spectral_shfl is only in a `make EXPERIMENTS=1` build")
     shape = (128, 9, 11)
     rng = np.random.default_rng(8)
     cube = rng.normal(size=shape)
     lsf = O.muse_like_lsf(128)
     fsf = np.ones((1, 1))
     outs = []
-    for knob in ("0", "1"):
-        monkeypatch.setenv("D3D_SPECTRAL_SHFL", knob)
-        with _lib.Engine(shape, fsf.shape) as eng:
+    for knob in (0, 1):
+        with _lib.Engine(shape, fsf.shape, options={"spectral_shfl": knob}) as eng:
             eng.set_taps(fsf, lsf)
             eng.upload_slot(_lib.SLOT_TMP0, cube)
             eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
@@ -210,7 +209,7 @@ def test_mh_chain_matches_oracle_update_by_update(name):
 
 
 @pytest.mark.parametrize("name", ["c1", "odd_depth", "big_fsf", "tiny"])
-def test_write_back_schemes_are_bit_identical(monkeypatch, name):
+def test_write_back_schemes_are_bit_identical(name):
     """Deferred write-back (wave-specialised k_mh_ws with three, one or two pending
     layers; k_mh_pair: two colour classes per launch with per-window G hand-off;
     k_mh_flow: one launch per sweep with per-window dependencies; plain
@@ -219,19 +218,15 @@ def test_write_back_schemes_are_bit_identical(monkeypatch, name):
     chains and residuals."""
     case = make_case(name)
     outs = []
-    for env in ({"D3D_MH_DEFER": "1"}, {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "1"},
-                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2"},
-                {"D3D_MH_DEFER": "1", "D3D_MH_LAYERS": "2", "D3D_MH_PAIR": "1"},  # k_mh_pair
-                {"D3D_MH_DEFER": "1", "D3D_MH_FLOW": "1"},
-                {"D3D_MH_DEFER": "2"},
-                {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "0"},
-                {"D3D_MH_DEFER": "0", "D3D_MH_MAXIT": "8"}):   # same workgroup size: same summation order
-        for k in ("D3D_MH_DEFER", "D3D_MH_MAXIT", "D3D_MH_NT", "D3D_MH_FLOW", "D3D_MH_LAYERS",
-                  "D3D_MH_PAIR"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        with engine_for(case) as eng:
+    from deconv3d_amd import _lib
+    variants = [{"mh_defer": 1}, {"mh_defer": 1, "mh_layers": 1}, {"mh_defer": 1, "mh_layers": 2},
+                {"mh_defer": 1, "mh_layers": 3}, {"mh_defer": 1, "mh_chain": 0}, {"mh_defer": 2},
+                {"mh_defer": 0, "mh_maxit": 0},
+                {"mh_defer": 0, "mh_maxit": 8}]   # same workgroup size: same summation order
+    if _lib.has_experiments():   # k_mh_pair / k_mh_flow: only in a `make EXPERIMENTS=1` build
+        variants += [{"mh_defer": 1, "mh_layers": 2, "mh_pair": 1}, {"mh_defer": 1, "mh_flow": 1}]
+    for opts in variants:
+        with engine_for(case, options=opts) as eng:
             eng.set_params(case["init"])
             eng.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=5, refresh_every=0)
             eng.mh_sweeps(2, 1)
@@ -245,26 +240,25 @@ def test_write_back_schemes_are_bit_identical(monkeypatch, name):
 
 @pytest.mark.parametrize("name", ["c1", "odd_depth", "big_fsf"])
 @pytest.mark.parametrize("how", ["scalar", "constant cube"])
-def test_uniform_variance_variant_is_bit_identical(monkeypatch, name, how):
+def test_uniform_variance_variant_is_bit_identical(name, how):
     """One constant variance (the reference's default, lib/run.py:171-178): the
     MH kernel takes 1/var from a register instead of SLOT_IVAR.  Same
-    arithmetic as the general kernel (D3D_UNIFORM_IVAR=0) -> bit-identical
+    arithmetic as the general kernel (option uniform_ivar = 0) -> bit-identical
     chains, residuals and delta maps; and it matches the oracle."""
     case = make_case(name)
     shape = (case["D"], case["H"], case["W"])
     v0 = float(np.median(case["var"]))
     var_cube = np.full(shape, v0)
     outs = []
-    for knob in ("1", "0"):
-        monkeypatch.setenv("D3D_UNIFORM_IVAR", knob)
+    for knob in (1, 0):
         from deconv3d_amd import _lib
-        with _lib.Engine(shape, case["fsf"].shape) as eng:
+        with _lib.Engine(shape, case["fsf"].shape, options={"uniform_ivar": knob}) as eng:
             eng.set_taps(case["fsf"], case["lsf"])
             if how == "scalar":
                 eng.set_data(case["data"], None, var_scalar=v0, mask=case["mask"])
             else:
                 eng.set_data(case["data"], var_cube, mask=case["mask"])
-            assert eng.variance_is_uniform() == (knob == "1")
+            assert eng.variance_is_uniform() == (knob == 1)
             eng.set_params(case["init"])
             eng.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=31, refresh_every=0)
             eng.mh_sweeps(2, 1)

@@ -283,6 +283,32 @@ def test_resume_continues_the_random_streams(tmp_path):
     assert not np.allclose(replay.chain[-1], whole.chain[-1], rtol=1e-3, atol=1e-3)
 
 
+def test_resumed_run_carries_the_acceptance_count_and_memmapped_checkpoints_share_a_prefix(tmp_path):
+    """(i) chain_file= and checkpoint= may name the same prefix -- the
+    checkpoint flushes the memory-mapped chain instead of rewriting the file under the
+    open mapping; (ii) the running acceptance rate of the stopping rule
+    (lib/run.py:344-359) is that of the whole chain, earlier segments included."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=4)
+    name = str(tmp_path / "same")
+    kw = dict(variance=var, seed=3, min_acceptance_rate=0., refresh_every=0)
+    first = d3d.Run(cube, inst, max_iterations=9, write_every=2, keep_one_in=1, checkpoint=name,
+                    chain_file=name, **kw)
+    plain = d3d.Run(cube, inst, max_iterations=9, keep_one_in=1, **kw)
+    np.testing.assert_array_equal(np.asarray(first.chain), plain.chain)
+    np.testing.assert_array_equal(np.load(name + "_chain.npy", mmap_mode="r"), plain.chain)
+    state = np.load(name + "_state.npz")
+    assert str(state["chain_file"]) == name
+    n_sp = 81
+    second = d3d.Run(cube, inst, max_iterations=5, initial_parameters=name + "_parameters.npy",
+                     resume_state=name + "_state.npz", **kw)
+    # whole-chain rate: accepted of both segments over the iterations of both
+    it_prev, acc_prev = int(state["total_iterations"]), int(state["total_accepted"])
+    assert second._it_base == it_prev - 1 and second._acc_base == acc_prev - n_sp
+    total_it = second.iterations_done + it_prev - 1
+    assert 0. < second.acceptance_rate <= 1.
+    assert abs(second.acceptance_rate * n_sp * total_it - round(second.acceptance_rate * n_sp * total_it)) < 1e-6
+
+
 def test_streamed_chain_equals_the_synchronous_one():
     """d3d_mh_sweeps streams saved sweeps through device snapshots, a copy stream and
     pinned buffers (more saved sweeps than buffers, so they are recycled): the chain

@@ -352,3 +352,59 @@ def test_bench_two_ranks_report_the_tiled_leg():
     assert leg["n_gpus"] == 2 and leg["scaling"] == "strong" and leg["value"] > 0
     assert "tiled 2x1" in leg["config"]["parallelism"]
     assert 0.0 < leg["acceptance"] < 1.0
+
+
+def test_a_larger_halo_plan_after_a_streamed_chain_leaves_the_streaming_buffers_alone():
+    """d3d_halo_plan used to free the chain-streaming buffers (device
+    snapshots, pinned ring, copy stream) when it grew the send buffer; the next streamed
+    sweep then copied through freed memory.  Stream a chain, grow the plan, stream again."""
+    case = make_case("tile_a")
+    D, H, W = case["D"], case["H"], case["W"]
+    with _lib.Engine((D, H, W), case["fsf"].shape) as eng, \
+            _lib.Engine((D, H, W), case["fsf"].shape) as ref:
+        for e in (eng, ref):
+            e.set_taps(case["fsf"], case["lsf"])
+            e.set_data(case["data"], case["var"], mask=case["mask"])
+            e.set_params(case["init"])
+            e.mh_config(case["min_b"], case["max_b"], 0.1, 35.0, seed=3, refresh_every=0)
+        chain = np.full((7, H, W, 3), np.nan)
+        want = np.full((7, H, W, 3), np.nan)
+        eng.halo_plan(_lib.PLAN_PARAMS, [[0, 0, 0, 2, 0, 3, 0, 2, 0, 3]])      # small plan
+        eng.mh_sweeps(3, 1, 1, chain=chain)
+        eng.halo_plan(_lib.PLAN_PARAMS, [[0, 0, 0, H, 0, W, 0, H, 0, W]])      # grows both buffers
+        eng.mh_sweeps(3, 4, 1, chain=chain)
+        ref.mh_sweeps(3, 1, 1, chain=want)
+        ref.mh_sweeps(3, 4, 1, chain=want)
+        np.testing.assert_array_equal(chain[1:], want[1:])
+
+
+def test_a_small_part_before_a_large_one_keeps_its_own_kernel_family():
+    """the pending-layer depth -- and with it the kernel family -- is chosen per
+    PART.  A part list whose first part is small (one layer) and whose second fills the
+    chip (two layers) used to fail with 'internal: 2 pending layers for a 1-layer
+    kernel'.  Against the oracle in part order."""
+    from tests.tiling_oracle import part_order
+    import bench as B
+    D, H, W, fs = 8, 300, 300, 11
+    fsf, lsf = B.build_taps(D, fs)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        data, var, truth, init, min_b, max_b = B.synthetic_inputs(eng, D, H, W, fsf, 5)
+        mask = np.ones((H, W))
+        eng.set_data(data, var, mask=mask)
+        parts = [(0, (0, 20, 0, W)), (1, (31, H, 0, W))]
+        eng.set_parts([r for _, r in parts], [ph for ph, _ in parts])
+        assert eng.mh_layers() == 2
+        eng.set_params(init)
+        ra = float(max_b[0] ** 2)
+        eng.mh_config(min_b, max_b, 0.1, ra, seed=11, refresh_every=0)
+        err0 = eng.residual()
+        accepted = eng.mh_sweeps(1, 1)
+        st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra, 11, err=err0)
+        for ph in (0, 1):
+            for (y, x) in part_order(parts, ph, mask, fs, fs):
+                O.mh_update(st, y, x, 1)
+        np.testing.assert_allclose(eng.get_params(), st.params, rtol=1e-9, atol=1e-9)
+        assert accepted == st.accepted
+        err = eng.download_slot(_lib.SLOT_ERR)
+        assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
