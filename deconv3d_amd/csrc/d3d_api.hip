@@ -229,6 +229,89 @@ int build_colour_lists(d3d_ctx *c) {
         // Launches that do not fill the chip are latency chains: a second layer only adds
         // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
         pt.layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
+        const bool partitioned = c->tiled || !c->part_rects.empty();
+        pt.wide = pt.layers == 1 && c->mh_wide && partitioned && c->Dp == 128 && most > 0 &&
+                  most <= c->flow_grid / 4 && c->mh_defer == 1;
+        // k_mh_chain: whole sweeps of the part in one launch of persistent workgroups, one per
+        // lattice slot -- where every slot is resident at once (one workgroup per CU) and a
+        // thread can hold its share of the window in registers
+        pt.chain = false;
+        pt.K = 0;
+        pt.last_col = -1;
+        for (int col = 0; col < ncol; ++col)
+            if (pt.real[col] > 0) {
+                ++pt.K;
+                pt.last_col = col;
+            }
+        if (!empty && pt.K > 0) {
+            const int cus = c->flow_grid / 4;
+            const int fhh_ = (c->fh - 1) / 2, fhw_ = (c->fw - 1) / 2;
+            // slot grid over the window centres [dy0 - fhh, dy1 + fhh) x [.., dx1 + fhw), its
+            // columns aligned with the colour order: slot column boundaries at the local
+            // residue of colour cx = 0, so that a slot's window moves right by one column
+            // per colour class along a row of colours
+            const int lx0 = ((0 - c->gx0) % c->fw + c->fw) % c->fw;
+            pt.chain_sx0 = (pt.dx0 - fhw_) - ((((pt.dx0 - fhw_) - lx0) % c->fw + c->fw) % c->fw);
+            pt.n_sy = (pt.dy1 - pt.dy0 + 2 * c->fh - 2) / c->fh;
+            pt.n_sx = (pt.dx1 + fhw_ - 1 - pt.chain_sx0) / c->fw + 1;
+            (void)fhh_;
+            // fw thread groups of HL threads hold the window's columns; + one deciding wavefront
+            pt.chain_ns = c->fw * c->HL;
+            const int nt = (pt.chain_ns + 63) / 64 * 64 + 64;
+            const bool fh_ok = c->fh == 3 || c->fh == 5 || c->fh == 7 || c->fh == 9 || c->fh == 11;
+            const double g_bytes = 4.0 * pt.K * pt.n_sy * pt.n_sx * c->Dp * 8.0;
+            const size_t lds = d3d::mh_chain_lds_doubles(c->fw, c->Dp, c->N, ncol, pt.K, nt / 64 - 1) * 8;
+            pt.chain = c->mh_chain_opt == 1 && c->mh_defer == 1 && c->Dp <= 256 && pt.layers == 1 &&
+                       (long)pt.n_sy * pt.n_sx <= cus && fh_ok && c->fw >= 3 && nt <= MH_CHAIN_NT &&
+                       c->Dp <= pt.chain_ns && lds <= (size_t)160 * 1024 && g_bytes <= 512e6 &&
+                       c->cube_elems * sizeof(double) < (size_t(1) << 31);
+        }
+    }
+    // device tables of the chain form
+    {
+        size_t need_slots = 0, need_G = 0;
+        std::vector<int2> cols((size_t)c->parts.size() * ncol, make_int2(0, 0));
+        bool any = false;
+        for (size_t pi = 0; pi < c->parts.size(); ++pi) {
+            const d3d_ctx::Part &pt = c->parts[pi];
+            if (!pt.chain) continue;
+            any = true;
+            need_slots = std::max(need_slots, (size_t)pt.n_sy * pt.n_sx);
+            need_G = std::max(need_G, (size_t)4 * pt.K * pt.n_sy * pt.n_sx * c->Dp);  // G rows | lines
+            int k = 0;
+            for (int col = 0; col < ncol; ++col)
+                if (pt.real[col] > 0)  // local residues of the (global) colour class
+                    cols[pi * ncol + k++] = make_int2(((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
+                                                      ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw);
+        }
+        if (any) {
+            if (cols.size() > c->chain_cols_cap) {
+                if (c->chain_cols) (void)hipFree(c->chain_cols);
+                c->chain_cols = nullptr;
+                c->chain_cols_cap = 0;
+                HIP_TRY(hipMalloc(&c->chain_cols, cols.size() * sizeof(int2)));
+                c->chain_cols_cap = cols.size();
+            }
+            HIP_TRY(hipMemcpyAsync(c->chain_cols, cols.data(), cols.size() * sizeof(int2),
+                                   hipMemcpyHostToDevice, c->stream));
+            if (need_slots > c->chain_slots_cap) {
+                if (c->chain_flags) (void)hipFree(c->chain_flags);
+                c->chain_flags = nullptr;
+                c->chain_slots_cap = 0;
+                HIP_TRY(hipMalloc(&c->chain_flags, 2 * need_slots * sizeof(unsigned)));
+                c->chain_slots_cap = need_slots;
+                HIP_TRY(hipMemsetAsync(c->chain_flags, 0, 2 * need_slots * sizeof(unsigned), c->stream));
+                c->chain_base = 0;
+            }
+            if (need_G > c->chain_G_cap) {
+                if (c->chain_G) (void)hipFree(c->chain_G);
+                c->chain_G = nullptr;
+                c->chain_G_cap = 0;
+                HIP_TRY(hipMalloc(&c->chain_G, need_G * sizeof(double)));
+                c->chain_G_cap = need_G;
+            }
+            HIP_TRY(hipStreamSynchronize(c->stream));  // `cols` goes out of scope
+        }
     }
     c->mh_layers = 1;
     for (const d3d_ctx::Part &pt : c->parts) c->mh_layers = std::max(c->mh_layers, pt.layers);
@@ -311,7 +394,7 @@ struct OptDesc {
 const OptDesc g_opts[] = {
     {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer, OPT_MH, 0, 2},
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
-    {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, -1, 1},
+    {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
     {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
@@ -526,7 +609,8 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->pair_state, c->sep_uv,
-                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep};
+                    c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep,
+                    c->chain_cols, c->chain_flags, c->chain_G};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -601,6 +685,12 @@ int d3d_ctx_set_option(d3d_ctx *c, const char *key, long value) {
 
 int d3d_ctx_get_option(d3d_ctx *c, const char *key, long *value) {
     NEED(c && key && value, D3D_ERR_INVALID, "NULL argument");
+    if (!strcmp(key, "chain_parts")) {  // read-only: parts whose sweeps run as ONE launch (k_mh_chain)
+        long n = 0;
+        for (const d3d_ctx::Part &pt : c->parts) n += pt.chain ? 1 : 0;
+        *value = c->have_data ? n : 0;
+        return D3D_OK;
+    }
     const OptDesc *o = find_opt(key);
     NEED(o, D3D_ERR_INVALID, "unknown option '%s'", key);
     *value = c->*(o->field);
@@ -1126,6 +1216,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
     if (c->lay_n && (c->pend_part != pi || !deferred))
         if (int rc = flush_pending(c)) return rc;
+    if (deferred && pt.chain) {  // all colours of the part in one launch
+        return launch_mh_chain(c, pi, sweep, 1);
+    }
     // two colour classes per launch (k_mh_pair) where the N/W alternation of two pending
     // layers allows it: an unpartitioned context, a launch that fills the chip
     const bool pairs = deferred && c->mh_pair && !partitioned && c->mh_defer == 1 && c->Dp <= 256 &&
@@ -1166,7 +1259,7 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
             // the launch that finds `layers` layers pending applies them for good
             P.write_back = (c->lay_n >= pt.layers) ? 1 : 0;
             const int g_cur = pend_free_buf(c);
-            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep, pt.layers);
+            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep, pt.layers, pt.wide);
             if (rc) return rc;
             if (P.write_back) c->lay_n = 0;
             // this launch's updates are the newest pending layer (local residues)
@@ -1229,8 +1322,27 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     const bool flow = c->mh_flow && c->mh_defer == 1 && !c->tiled && c->parts.size() == 1 &&
                       c->Dp <= 256 && c->flow_K > 0 &&
                       c->cube_elems * sizeof(double) < (size_t(1) << 31);
+    // One part, no halo plans, the chain form: several sweeps per launch -- up to the next
+    // sweep that is saved or followed by a from-scratch residual.
+    const bool chain_batches = !flow && !any_plan && c->parts.size() == 1 && c->parts[0].chain &&
+                               c->mh_defer == 1 && n_phases == 1;
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
         const uint32_t rs = (uint32_t)s + c->sweep_origin;
+        if (chain_batches) {
+            int last = first_sweep + n_sweeps - 1;  // last sweep of this launch
+            for (int t = s; t <= last; ++t) {
+                const bool saved = t % keep_one_in == 0 && (chain_out || dlog_out);
+                const bool refresh = c->refresh_every > 0 && t % c->refresh_every == 0;
+                if (saved || refresh) {
+                    last = t;
+                    break;
+                }
+            }
+            if (c->lay_n && c->pend_part != 0)
+                if (int rc = flush_pending(c)) return rc;
+            if (int rc = launch_mh_chain(c, 0, rs, last - s + 1)) return rc;
+            s = last;
+        } else
 #ifdef D3D_EXPERIMENTS
         if (flow) {
             c->pend_part = 0;
@@ -1270,15 +1382,18 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     unsigned long long acc = 0;
     unsigned flow_err = 0;
     HIP_TRY(hipMemcpyAsync(&acc, c->accepted, sizeof acc, hipMemcpyDeviceToHost, c->stream));
-    if (flow || c->mh_pair)  // (both kernels raise *flow_err when a flag wait times out)
+    if (flow || c->mh_pair || c->chain_used)  // (these kernels raise *flow_err when a flag wait times out)
         HIP_TRY(hipMemcpyAsync(&flow_err, c->flow_err, sizeof flow_err, hipMemcpyDeviceToHost,
                                c->stream));
     while (snaps.count > 0)
         if (int rc = snap_drain_one(c, snaps, chain_out, dlog_out)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (accepted) *accepted = (int64_t)acc;
+    c->chain_used = false;
     NEED(!flow_err, D3D_ERR_HIP,
-         "k_mh_flow / k_mh_pair: a dependency wait timed out; the chain state is invalid");
+         "a dependency wait inside a sweep kernel timed out (k_mh_chain needs all its workgroups "
+         "resident: is another process using this GPU?  option mh_chain = 0 avoids it); the "
+         "chain state is invalid");
     return D3D_OK;
 }
 
@@ -1351,6 +1466,18 @@ int d3d_x_stamps_read(d3d_ctx *c, int launch, int n, unsigned long long *out) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->stampbuf + (size_t)launch * c->stamp_stride,
                       (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return D3D_OK;
+}
+
+// the whole stamp buffer from word `first` on (k_mh_chain: [slot][colour][8], tools/chain_phases.py)
+int d3d_x_stamps_raw(d3d_ctx *c, long first, long nwords, unsigned long long *out) {
+    NEED(c && out && c->stampbuf && first >= 0 && nwords > 0 &&
+             (size_t)(first + nwords) <= c->stamp_launches * c->stamp_stride,
+         D3D_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->stampbuf + first, (size_t)nwords * sizeof(unsigned long long),
+                      hipMemcpyDeviceToHost));
     return D3D_OK;
 }
 #endif

@@ -19,6 +19,14 @@
 #include "../../include/deconv3d_hip.h"
 #include "d3d_kernels.h"
 
+// The WIDE form of a small colour launch at 128 channels: eleven
+// streaming wavefronts per window instead of four -- one per window row of an 11 x 11 FSF
+// -- in workgroups of 768 threads.
+constexpr int MH_WIDE_NS = 704;
+// k_mh_chain: at most this many threads per workgroup (three wavefronts per SIMD: 168
+// registers each, of which a thread's column of an 11-row window takes 88)
+constexpr int MH_CHAIN_NT = 768;
+
 namespace d3dh {
 // sets the thread-local message d3d_last_error() returns; returns `code`
 int fail(int code, const char *fmt, ...);
@@ -73,6 +81,11 @@ struct d3d_ctx {
         int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;  // domain (local)
         int phase = 0;
         int layers = 1;                          // pending layers in use
+        bool wide = false;                       // its colour launches take the 960-thread form
+        // k_mh_chain (whole sweeps of the part in one launch): slot grid, or chain = false
+        bool chain = false;
+        int chain_ns = 0, chain_sx0 = 0, n_sy = 0, n_sx = 0, K = 0;
+        int last_col = -1;                       // its last active colour
         std::vector<int> off;                    // fh*fw + 1: start of each colour's list in spx
         std::vector<int> real;                   // fh*fw: real spaxels of each colour
     };
@@ -142,7 +155,18 @@ struct d3d_ctx {
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
     // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
     // monotonic ticket counter, so that nothing needs clearing between launches
-    int mh_chain_opt = -1;         // option mh_chain: -1 where it pays (small parts), 0 never, 1 wherever it fits
+    int mh_chain_opt = 0;          // option mh_chain: 1 = k_mh_chain wherever a part's slots are all resident;
+                                   // 0 (default): colour launches -- the chain kernel measures 5-25 % SLOWER
+                                   // (one CU per window is bound by its own VALU and
+                                   // hand-off latencies, not by the kernel boundary it removes)
+    int2 *chain_cols = nullptr;    // [parts][fh*fw] local residues of each part's active colours
+    size_t chain_cols_cap = 0;
+    unsigned *chain_flags = nullptr;  // [2][chain_slots_cap]: flag1 | flag2 (monotonic epochs)
+    size_t chain_slots_cap = 0;
+    double *chain_G = nullptr;     // [2][K][slots][Dp] G rows | [slots][K][2][Dp] unit lines of a sweep
+    size_t chain_G_cap = 0;
+    unsigned chain_base = 0;       // the epoch every flag of a finished launch holds
+    bool chain_used = false;       // a chain launch ran since the error word was last read
     int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)
@@ -227,8 +251,11 @@ int pend_free_buf(const d3d_ctx *c);
 void pend_push(d3d_ctx *c, int cy, int cx, int g);
 void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P);
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep);
-int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers);
+int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
+                    bool wide);
 int flush_pending(d3d_ctx *c);
+// n_sweeps whole sweeps (Philox numbers sweep0 ..) of part pi in one launch (Part::chain)
+int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps);
 int launch_apply_updates(d3d_ctx *c, const d3d::MHArgs &P, const double *rec, int n);
 int launch_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma, uint64_t seed,
                   int wave_mode, double *buf);

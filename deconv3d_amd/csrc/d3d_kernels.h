@@ -1722,6 +1722,7 @@ __device__ __forceinline__ void mh_channel_sums(const MHArgs &P, const MHShared 
     const double Lo = q.a_old * EO;
     double Az = 0.0, Bz = 0.0, Cz = 0.0;
     if (ch < D) {
+#pragma unroll 4
         for (int gg = 0; gg < G; ++gg) {
             const double *r = S.red + (size_t)gg * 3 * Dp + ch;
             Az += r[0];
@@ -2576,34 +2577,46 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
 // ---- whole sweeps of a small part in ONE launch: persistent workgroups ----------------------
 //
 // A colour launch that does not fill the chip is a latency chain: setup,
-// proposal -> lines -> LSF on one wavefront, the window's round trips, the decision, the kernel
-// boundary -- 12-15 us per colour however few windows it holds, 121 times per sweep.  k_mh_chain
-// keeps ONE workgroup per lattice slot resident for all colours of all sweeps of the launch:
+// proposal -> lines -> LSF on one wavefront, the decision, the kernel boundary -- and above
+// all ONE compute unit pulling a whole window (242 KB at 128 channels, 11 x 11) through its
+// own memory port at 30-45 GB/s: 12-15 us per colour however few windows the launch holds,
+// 121 times per sweep.  k_mh_chain keeps ONE workgroup per lattice slot resident for all
+// colours of all sweeps of the launch, and the slot's window in REGISTERS:
 //
 //   * slot (iy, ix) owns the window centres [sy0 + iy*fh, +fh) x [sx0 + ix*fw, +fw): exactly
 //     one lattice point of every colour class, so the windows of one colour -- real spaxels and
-//     the virtual positions that only apply pending updates -- still tile the part's domain;
-//   * the residual keeps ONE pending layer, as k_mh_ws with one layer does: colour k applies
-//     colour k-1's update e += f G while it accumulates its own window sums, and stores e;
+//     the virtual positions that only apply pending updates -- still tile the part's domain.
+//     The slot grid is aligned with the colour order: along a row of colour classes
+//     (cy fixed, cx = 0 .. fw-1) a slot's window moves right by ONE column per colour;
+//   * a thread group (HL threads, one z-pair each) holds one absolute COLUMN of the window,
+//     fh rows of residual and 1/variance, in registers across colours.  When the window
+//     slides, ten of its eleven columns stay where they are: only the entering column is
+//     loaded and only the leaving one stored -- 1/11 of the traffic of a colour launch.  The
+//     registers stay current because every update of a cell is applied to them: the
+//     predecessor colour's G rows (the slot's own among them) are applied in registers,
+//     exactly as k_mh_ws applies a pending layer; memory is brought up to date for the cells
+//     another workgroup reads next (the leaving column), and for all of them where the next
+//     colour starts a new row of colours (everybody reloads) or the launch ends;
 //   * a window of colour k depends on the <= 4 windows of colour k-1 that intersect it, through
 //     two monotonic epoch flags per slot: flag1 = "residual stores of colour E complete"
-//     (raised while the slot's decision is still being taken) and flag2 = "G row of colour E
-//     published".  A workgroup loads its window as soon as its predecessors' flag1 is up --
-//     during their decisions -- and holds it in REGISTERS (UT positions per thread); when
-//     their flag2 follows, the four G rows (4 KiB) are all that is left on the critical path:
+//     and flag2 = "G row of colour E published".  The critical path of a colour is
 //     decision -> G row -> flag -> G rows -> apply + accumulate from registers -> decision;
-//   * everything that does not depend on the window is taken off that path: the proposals of
-//     a whole sweep (Philox, tan, log: they depend on nothing the sweep changes) are computed
+//   * everything that does not depend on the window is off that path: the proposals of a
+//     whole sweep (Philox, tan, log: they depend on nothing the sweep changes) are computed
 //     at its start, one colour per thread; position table, unit lines and their LSF
 //     convolution of colour k+1 are built by the streaming wavefronts while the extra
 //     wavefront takes colour k's decision;
 //   * hand-off (cdna_hip_programming.md Guideline 16, the all-sc1 form): every residual and
-//     G-row byte is stored write-through (sc1) and loaded sc1; every storing wavefront
-//     drains (vmcnt(0)) and counts itself in LDS, the last one raises the flag (an sc1
-//     store); every wavefront that loads handed-off bytes polls the flags itself first.
+//     G-row byte that crosses workgroups is stored write-through (sc1) and loaded sc1; every
+//     storing wavefront drains (vmcnt(0)) and counts itself in LDS, the last one raises the
+//     flag (an sc1 store); every wavefront that loads handed-off bytes polls the flags itself.
 //
-// Same windows, same order of the same operations as one k_mh_ws<NS> launch per colour with
-// one pending layer: bit-identical chains (tests/test_gpu_chain.py).  Every spin has a
+// Window sums are grouped by window COLUMN (the thread group that holds it accumulates its
+// fh rows top to bottom; the columns are then added left to right): another grouping than
+// the colour launches' (position p -> group p mod G), so the two agree to rounding, not bit
+// for bit -- like every other regrouping of these sums, both match the oracle to 1e-9
+// (tests/test_gpu_chain.py).  The chain kernel itself is deterministic and independent of
+// how sweeps are cut into launches and of tiling (same parts, same bits).  Every spin has a
 // wall-clock bound that raises *F.err and lets the grid drain; the host launches the kernel
 // only when all slots are resident at once (one workgroup per CU).
 struct MHChain {
@@ -2615,12 +2628,14 @@ struct MHChain {
     double *Gout;       // the LAST colour's rows in the library's regular indexing
                         // ((y/fh)*slots_x + x/fw): the pending layer the launch leaves
     int K, n_sy, n_sx;  // active colours; slot grid
-    int sy0, sx0;       // window centres of slot (0,0) start here
+    int sy0, sx0;       // window centres of slot (0,0) start here (sx0 aligned with colour cx = 0)
     int py0, py1, px0, px1;  // the part's rectangle: its unmasked spaxels are the real ones
     unsigned base;      // every flag holds `base` when the launch starts
     uint32_t sweep0;    // Philox sweep number of the first sweep
     int n_sweeps;
-    int zigzag;
+    int NS;             // threads that hold a column: fw thread groups of HL threads
+    double *lines;      // [slots][K][2][Dp] scratch: LSF-convolved unit lines of a sweep's colours
+    int dbg;            // EXPERIMENTS builds: timing-only switches (wrong results), else 0
 };
 
 __device__ __forceinline__ int covering_lattice(int q, int c, int per, int hw) {
@@ -2650,11 +2665,17 @@ __device__ __forceinline__ bool chain_wait(const unsigned *addr, unsigned want, 
 }
 
 constexpr int MH_PROP_DOUBLES = (sizeof(MHProposal) + 7) / 8;
+constexpr int MH_CHAIN_GEO = 12;    // ints of a colour's geometry at a slot (k_mh_chain)
+constexpr int MH_CHAIN_CHUNK = 8;   // colours whose unit lines are staged in LDS at a time
 
-__host__ __device__ inline size_t mh_chain_lds_doubles(int NS, int HL, int Dp, int N, int npos,
-                                                       int K) {
-    // k_mh_ws's regions | proposals of a sweep | parameters after each colour's update | control
-    return mh_ws_lds_doubles(NS, HL, Dp, N, npos, 1) + (size_t)K * (MH_PROP_DOUBLES + 3) + 4;
+// LDS of k_mh_chain, in doubles: taps | 4 staged G rows | column partial sums | unit lines of
+// a chunk of colours | wave sums + verdict | proposals of a sweep | parameters after each
+// colour's update | geometry of each colour | control words
+__host__ __device__ inline size_t mh_chain_lds_doubles(int fw, int Dp, int N, int npos, int K,
+                                                       int nwaves) {
+    return (size_t)npos + 1 + (size_t)Dp + (size_t)fw * 3 * Dp + (size_t)MH_CHAIN_CHUNK * 2 * N +
+           8 * (size_t)nwaves + 8 + (size_t)K * (MH_PROP_DOUBLES + 3) +
+           ((size_t)K * MH_CHAIN_GEO + 1) / 2 + 4;
 }
 
 // lattice point of residue r in [lo, lo + per)
@@ -2674,140 +2695,141 @@ __device__ __forceinline__ int chain_lattice_point(int lo, int r, int per) {
 #define D3D_CHAIN_STAMP(j)
 #endif
 
-template <int NS, bool UV, int UT>
-__global__ __launch_bounds__(NS + 64) void k_mh_chain(MHArgs P, MHChain F) {
+// FH = fh, the window's rows: a thread holds FH z-pairs of residual and of 1/variance.
+// NTMAX: upper bound of the workgroup size (fw*HL rounded up to wavefronts + 64), which sets
+// the register budget.
+template <int FH, bool UV, int NTMAX>
+__global__ __launch_bounds__(NTMAX) void k_mh_chain(MHArgs P, MHChain F) {
     extern __shared__ double smem[];
-    constexpr int NT = NS + 64;
-    constexpr int NW = NS / 64;  // streaming wavefronts 0 .. NW-1; wavefront NW decides
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
+    int tid = tid0, lane = tid & 63, wave = tid >> 6;
     const int HL = P.HL, Dp = P.Dp, N = P.N, npos = P.npos;
-    const int G = NS / HL;
-    const int fh = P.fh, fw = P.fw, fhh = (fh - 1) / 2, fhw = (fw - 1) / 2;
-    const MHShared S = mh_carve(smem, NS, HL, Dp, N, npos, 1);
-    double *sEN = S.sum + 8 * NW + 8;
-    double *xb = smem + mh_ws_lds_doubles(NS, HL, Dp, N, npos, 1);
+    const int fh = FH, fw = P.fw, fhh = (FH - 1) / 2, fhw = (fw - 1) / 2;
+    const int NS = F.NS;                   // threads that hold a column
+    const int NW = (NS + 63) / 64;         // streaming wavefronts 0 .. NW-1; wavefront NW decides
+    const int NT = NW * 64 + 64;
+    MHShared S;
+    S.fsf = smem;                                     // [npos + 1]: the last entry is a zero tap
+    S.pos = nullptr;
+    S.gp = nullptr;
+    S.G = S.fsf + npos + 1;                           // [Dp] this slot's own latest G row
+    S.red = S.G + Dp;
+    S.gO = S.red + (size_t)fw * 3 * Dp;               // [CHUNK][2][N] unit lines of a chunk of colours
+    S.gN = nullptr;
+    S.sum = S.gO + (size_t)MH_CHAIN_CHUNK * 2 * N;
+    double *xb = S.sum + 8 * (size_t)NW + 8;
     MHProposal *sprop = reinterpret_cast<MHProposal *>(xb);   // [K]
     double *snew = xb + (size_t)F.K * MH_PROP_DOUBLES;        // [K][3]
-    unsigned *sctl = reinterpret_cast<unsigned *>(snew + 3 * (size_t)F.K);  // drain counters
-    const bool streamer = tid < NS;
-    const int g = tid / HL, zl = tid - g * HL;  // streaming thread: position group, z-pair
-    const bool has_window = streamer && g < G;
+    int *sgeo = reinterpret_cast<int *>(snew + 3 * (size_t)F.K);  // [K][MH_CHAIN_GEO]
+    unsigned *sctl = reinterpret_cast<unsigned *>(snew + 3 * (size_t)F.K +
+                                                  ((size_t)F.K * MH_CHAIN_GEO + 1) / 2);
+    bool streamer = tid < NW * 64;         // (threads NS .. NW*64-1 hold no column)
+    int gcol = tid / HL, zl = tid - gcol * HL;  // column group, z-pair
+    bool has_column = tid < NS;
     const int slots = F.n_sy * F.n_sx;
     const int slot = blockIdx.x;
     const int iy = slot / F.n_sx, ix = slot - iy * F.n_sx;
     const int ylo = F.sy0 + iy * fh, xlo = F.sx0 + ix * fw;
     const int nstore = (Dp + 63) / 64;  // wavefronts that store the G row
+    // LSF-convolved unit lines E_old, E_new of every colour of the sweep, this slot's
+    double *lines = F.lines + (size_t)slot * F.K * 2 * Dp;
 
-    for (int p = tid; p < npos; p += NT) S.fsf[p] = P.fsf[p];
+    for (int p = tid; p <= npos; p += NT) S.fsf[p] = (p < npos) ? P.fsf[p] : 0.0;
     if (tid < 4) sctl[tid] = 0u;
+    if (tid < Dp) S.G[tid] = 0.0;
 
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     union { double2 d; v4u i; } cv;
     // raw buffer over SLOT_ERR (the launcher checks that it is < 2 GiB); aux 16 = sc1
     const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         P.err, 0, (int)((long)P.H * P.W * Dp * 8), 0x00020000);
-    // the padding channel of an odd depth carries 1/var = 0
-    const double2 vu = make_double2(P.ivar_uniform, (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
 
-    // geometry of a colour at this slot; everything here is uniform over the workgroup
+    // Geometry of a colour at this slot (uniform over the workgroup; computed once per
+    // sweep by one thread per colour, kept in LDS, read into scalar registers per colour).
     struct Geo {
-        int y, x, present, real, have_pred, rev, pk, pring;
-        int py0l, py1l, px0l, px1l;  // lattice points of the previous colour at the window's corners
-        MHWsItem I;
+        int y, x;
+        int flags;  // 1 present (the window meets the domain) | 2 real | 4 a predecessor colour exists
+        int pk, pring;               // the predecessor colour's ordinal and ring half
+        int py0, py1, px0, px1;      // its lattice points at the window's corners (clipped to the domain)
     };
     auto geometry = [&](int si, int k) {
         Geo c;
         const int2 col = F.cols[k];
         c.y = chain_lattice_point(ylo, col.x, fh);
         c.x = chain_lattice_point(xlo, col.y, fw);
-        // (the window reaches the domain's upper/left edge by construction of the slot grid)
-        c.present = (c.y - fhh < P.dy1) && (c.x - fhw < P.dx1);
-        c.real = 0;
-        if (c.present && c.y >= F.py0 && c.y < F.py1 && c.x >= F.px0 && c.x < F.px1)
-            c.real = P.mask[c.y * P.W + c.x] != 0;
-        c.have_pred = (si | k) != 0;
+        // (the window reaches the domain's upper/left edge by construction of the slot grid,
+        // except in the extra slot column the alignment of the grid may add on the left)
+        const bool present = (c.y - fhh < P.dy1) && (c.x - fhw < P.dx1) && (c.x + fhw >= P.dx0);
+        bool real = false;
+        if (present && c.y >= F.py0 && c.y < F.py1 && c.x >= F.px0 && c.x < F.px1)
+            real = P.mask[c.y * P.W + c.x] != 0;
+        c.flags = (present ? 1 : 0) | (real ? 2 : 0) | ((si | k) ? 4 : 0);
         c.pk = k ? k - 1 : F.K - 1;
         c.pring = k ? (si & 1) : ((si + 1) & 1);
-        c.rev = (F.zigzag && (k & 1)) ? 1 : 0;
         const int2 pc = F.cols[c.pk];
-        c.py0l = covering_lattice(max(c.y - fhh, P.dy0), pc.x, fh, fhh);
-        c.py1l = covering_lattice(min(c.y + fhh, P.dy1 - 1), pc.x, fh, fhh);
-        c.px0l = covering_lattice(max(c.x - fhw, P.dx0), pc.y, fw, fhw);
-        c.px1l = covering_lattice(min(c.x + fhw, P.dx1 - 1), pc.y, fw, fhw);
-        c.I.y = c.y;
-        c.I.x = c.x;
-        c.I.real = c.real;
-        c.I.n_lay = c.have_pred ? 1 : 0;
-        c.I.write_back = 1;
-        c.I.rev = c.rev;
-#pragma unroll
-        for (int j = 0; j < MH_LAYERS; ++j) {
-            c.I.lay_cy[j] = pc.x;
-            c.I.lay_cx[j] = pc.y;
-            c.I.lay_G[j] = nullptr;
-        }
-        c.I.Gcur = nullptr;
-        mh_ws_preds<1>(P, c.I);
+        c.py0 = covering_lattice(max(c.y - fhh, P.dy0), pc.x, fh, fhh);
+        c.py1 = covering_lattice(min(c.y + fhh, P.dy1 - 1), pc.x, fh, fhh);
+        c.px0 = covering_lattice(max(c.x - fhw, P.dx0), pc.y, fw, fhw);
+        c.px1 = covering_lattice(min(c.x + fhw, P.dx1 - 1), pc.y, fw, fhw);
+        return c;
+    };
+    auto load_geo = [&](int k) {
+        const int *gq = sgeo + k * MH_CHAIN_GEO;
+        Geo c;
+        c.y = __builtin_amdgcn_readfirstlane(gq[0]);
+        c.x = __builtin_amdgcn_readfirstlane(gq[1]);
+        c.flags = __builtin_amdgcn_readfirstlane(gq[2]);
+        c.pk = __builtin_amdgcn_readfirstlane(gq[3]);
+        c.pring = __builtin_amdgcn_readfirstlane(gq[4]);
+        c.py0 = __builtin_amdgcn_readfirstlane(gq[5]);
+        c.py1 = __builtin_amdgcn_readfirstlane(gq[6]);
+        c.px0 = __builtin_amdgcn_readfirstlane(gq[7]);
+        c.px1 = __builtin_amdgcn_readfirstlane(gq[8]);
         return c;
     };
     // slot of a lattice point of the slot grid
     auto slot_of = [&](int sy, int sx) { return ((sy - F.sy0) / fh) * F.n_sx + (sx - F.sx0) / fw; };
 
-    // position table (by the threads t0 .. t0+nt-1), and unit lines + their LSF convolution
-    // (by ONE wavefront: wave-private, no block barrier) of a colour
-    auto build_table = [&](const Geo &c, int t0, int nt) {
-        if (!c.present) return;
-        for (int p = tid - t0; p < npos; p += nt) {
-            const int dy = p / fw, dx = p - dy * fw;
-            const int yy = c.y + dy - fhh, xx = c.x + dx - fhw;
-            const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
-            S.pos[2 * p] = inside ? yy * P.W + xx : -1;
-            int code = -1;
-            if (inside && c.have_pred) {
-                const int sy = covering_coord(yy, c.I.lay_cy[0], fh, fhh, P.H);
-                const int sx = covering_coord(xx, c.I.lay_cx[0], fw, fhw, P.W);
-                if (sy >= 0 && sx >= 0)
-                    code = ((yy - sy + fhh) * fw + (xx - sx + fhw)) |
-                           (((sy == c.I.psy0[0] ? 0 : 2) + (sx == c.I.psx0[0] ? 0 : 1)) << 16);
-            }
-            S.pos[2 * p + 1] = code;
-        }
-    };
-    auto build_lines = [&](const Geo &c, int k) {
-        if (!c.real) return;
-        const MHProposal q = sprop[k];
-        for (int j = lane; j < N; j += 64) {
-            S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
-            S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
-        }
-        __builtin_amdgcn_wave_barrier();  // wave-private region: LDS is in order per wave
-        for (int ch = lane; ch < Dp; ch += 64) {
-            double EO, EN;
-            mh_lsf(P, S.gO, S.gN, ch, &EO, &EN);
-            S.G[ch] = EO;
-            sEN[ch] = EN;
-        }
-    };
+    // the window: column X of this thread group, FH rows, one z-pair per thread
+    double2 e[FH], v[FH];
+#pragma unroll
+    for (int r = 0; r < FH; ++r) {
+        e[r] = make_double2(0.0, 0.0);
+        // the padding channel of an odd depth carries 1/var = 0
+        v[r] = make_double2(P.ivar_uniform, (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
+    }
+    int held_xl = 0, held_y = 0;
+    bool held = false;  // the registers hold the window rows of held_y, columns [held_xl, held_xl + fw)
+    int prev_y = -(1 << 30), prev_x = -(1 << 30);  // this slot's lattice point of the previous colour
 
     bool ok = true;
     for (int si = 0; si < F.n_sweeps; ++si) {
         const uint32_t sweep = F.sweep0 + (uint32_t)si;
-        // Sweep start.  The 3 x 3 neighbourhood has completed the previous sweep: none of
+        // ---- sweep start.  The 3 x 3 neighbourhood has completed the previous sweep: none of
         // its workgroups still reads a G row of the ring half this sweep overwrites.
         if (si > 0 && wave == 0 && lane < 9) {
             const int ny = iy + lane / 3 - 1, nx = ix + lane % 3 - 1;
             if (ny >= 0 && ny < F.n_sy && nx >= 0 && nx < F.n_sx)
                 ok = chain_wait(F.flag2 + ny * F.n_sx + nx, F.base + (unsigned)(si * F.K), F.err);
         }
-        // The proposals of the whole sweep, one colour per thread: they depend on the
-        // spaxel's own parameters and its Philox stream only (lib/run.py:369-388).
+        // Geometry and proposal of every colour, one colour per thread: they depend on the
+        // spaxel's own parameters and its Philox stream only (lib/run.py:369-388) -- on
+        // nothing this sweep changes before the colour's turn.
         for (int k2 = tid; k2 < F.K; k2 += NT) {
-            const int2 col = F.cols[k2];
-            const int y = chain_lattice_point(ylo, col.x, fh), x = chain_lattice_point(xlo, col.y, fw);
-            if (y >= F.py0 && y < F.py1 && x >= F.px0 && x < F.px1 && P.mask[y * P.W + x]) {
-                const long sp = (long)y * P.W + x;
-                const uint32_t gsp = (uint32_t)((y + P.gy0) * P.Wg + (x + P.gx0));
+            const Geo c = geometry(si, k2);
+            int *gq = sgeo + k2 * MH_CHAIN_GEO;
+            gq[0] = c.y;
+            gq[1] = c.x;
+            gq[2] = c.flags;
+            gq[3] = c.pk;
+            gq[4] = c.pring;
+            gq[5] = c.py0;
+            gq[6] = c.py1;
+            gq[7] = c.px0;
+            gq[8] = c.px1;
+            if (c.flags & 2) {
+                const long sp = (long)c.y * P.W + c.x;
+                const uint32_t gsp = (uint32_t)((c.y + P.gy0) * P.Wg + (c.x + P.gx0));
                 const double a = si ? snew[3 * k2 + 0] : P.params[sp * 3 + 0];
                 const double cc = si ? snew[3 * k2 + 1] : P.params[sp * 3 + 1];
                 const double w = si ? snew[3 * k2 + 2] : P.params[sp * 3 + 2];
@@ -2815,126 +2837,228 @@ __global__ __launch_bounds__(NS + 64) void k_mh_chain(MHArgs P, MHChain F) {
             }
         }
         if (__syncthreads_or(!ok)) return;  // a timed-out wait: *F.err is set, the host reports it
-        Geo cur = geometry(si, 0);
-        build_table(cur, 0, NT);
-        if (wave == 0) build_lines(cur, 0);
+        // The LSF-convolved unit lines of every colour (lib/line_models.py:109,
+        // lib/convolution.py:89-120), a chunk of colours at a time through LDS, into this
+        // slot's scratch rows; the colour loop reads them back with sc1 loads.
+        for (int k0 = 0; k0 < F.K; k0 += MH_CHAIN_CHUNK) {
+            const int nk = min(MH_CHAIN_CHUNK, F.K - k0);
+            for (int i = tid; i < nk * N; i += NT) {
+                const int kk = i / N, j = i - kk * N;
+                double go = 0.0, gn = 0.0;
+                if ((sgeo[(k0 + kk) * MH_CHAIN_GEO + 2] & 2) && j < P.D) {
+                    const MHProposal &q = sprop[k0 + kk];
+                    go = unit_gaussian((double)j, q.c_old, q.w_old);
+                    gn = unit_gaussian((double)j, q.pn[1], q.pn[2]);
+                }
+                S.gO[(size_t)kk * 2 * N + j] = go;
+                S.gO[(size_t)kk * 2 * N + N + j] = gn;
+            }
+            __syncthreads();
+            for (int i = tid; i < nk * Dp; i += NT) {
+                const int kk = i / Dp, ch = i - kk * Dp;
+                if (sgeo[(k0 + kk) * MH_CHAIN_GEO + 2] & 2) {
+                    double EO, EN;
+                    mh_lsf(P, S.gO + (size_t)kk * 2 * N, S.gO + (size_t)kk * 2 * N + N, ch, &EO, &EN);
+                    double *dst = lines + (size_t)(k0 + kk) * 2 * Dp + ch;
+                    dst[0] = EO;
+                    dst[Dp] = EN;
+                }
+            }
+            __syncthreads();
+        }
+        // (the lines were stored by other wavefronts of this workgroup: drained here, read
+        // past the L1 below)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        Geo cur = load_geo(0);
+        double EO = 0.0, EN = 0.0;  // this thread's channel of the current colour's lines
+        if ((cur.flags & 2) && tid < Dp) {
+            EO = __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<const unsigned long long *>(lines + tid), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT));
+            EN = __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<const unsigned long long *>(lines + Dp + tid), __ATOMIC_RELAXED,
+                __HIP_MEMORY_SCOPE_AGENT));
+        }
 
         for (int k = 0; k < F.K; ++k) {
             const unsigned E = F.base + (unsigned)(si * F.K + k) + 1u;
-            const int sp = cur.y * P.W + cur.x;
+            // (the thread index made opaque per colour: what derives from it is recomputed
+            // here instead of being hoisted into registers that live for the whole kernel)
+            tid = tid0;
+            asm volatile("" : "+v"(tid));
+            lane = tid & 63;
+            wave = tid >> 6;
+            streamer = tid < NW * 64;
+            gcol = tid / HL;
+            zl = tid - gcol * HL;
+            has_column = tid < NS;
+            const bool present = cur.flags & 1, real = cur.flags & 2, have_pred = cur.flags & 4;
+            const bool last = (k + 1 == F.K) && (si + 1 == F.n_sweeps);
+            // the next colour of THIS sweep (a sweep's last colour is followed by a reload)
+            const bool more = k + 1 < F.K;
+            const Geo nxt = more ? load_geo(k + 1) : cur;
             D3D_CHAIN_STAMP(0);
-            // ---- (1) the window into registers, as soon as the predecessors have stored it
-            int vox[UT];
-            double2 e[UT], v[UT];
-            const bool loads = has_window && cur.present && (cur.real || cur.have_pred);
-            if (streamer && cur.present && cur.have_pred) {
-                if (lane < 4)
-                    ok = chain_wait(F.flag1 + slot_of((lane & 2) ? cur.py1l : cur.py0l,
-                                                      (lane & 1) ? cur.px1l : cur.px0l),
-                                    E - 1u, F.err);
-                ok = __all(ok);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // keep the loads below the poll
-            }
+            const int xl = cur.x - fhw, yt = cur.y - fhh;    // the window's left column, top row
+            // ---- per ROW of the window, uniform over the workgroup (scalar registers): is it
+            // inside the domain; which of the previous colour's two lattice rows (py0 above,
+            // py1 below) updated it, and with which tap row
+            unsigned in_rows = 0u, upd_rows = 0u;
+            const bool sy0_ok = have_pred && cur.py0 >= 0 && cur.py0 < P.H;
+            const bool sy1_ok = have_pred && cur.py1 >= 0 && cur.py1 < P.H;
+            const int rb = cur.py0 + fhh - yt + 1;           // rows r >= rb belong to py1
 #pragma unroll
-            for (int i = 0; i < UT; ++i) {
-                const int pw = g + i * G;
-                const int p = cur.rev ? npos - 1 - pw : pw;
-                vox[i] = (loads && pw < npos) ? S.pos[2 * p] : -1;
-                e[i] = make_double2(0.0, 0.0);
-                v[i] = vu;
-                if (vox[i] >= 0) {
-                    const long idx = (long)vox[i] * Dp + 2 * zl;
-                    cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
-                    e[i] = cv.d;
-                    if (!UV) v[i] = *reinterpret_cast<const double2 *>(P.ivar + idx);
-                }
+            for (int r = 0; r < FH; ++r) {
+                const int yy = yt + r;
+                const bool in = yy >= P.dy0 && yy < P.dy1;
+                in_rows |= (in ? 1u : 0u) << r;
+                upd_rows |= ((in && (r >= rb ? sy1_ok : sy0_ok)) ? 1u : 0u) << r;
             }
-            D3D_CHAIN_STAMP(1);
-            // ---- (2) the predecessors' G rows (sc1 loads) into LDS
-            if (streamer && cur.present && cur.have_pred) {
-                if (lane < 4)
-                    ok = ok && chain_wait(F.flag2 + slot_of((lane & 2) ? cur.py1l : cur.py0l,
-                                                            (lane & 1) ? cur.px1l : cur.px0l),
-                                          E - 1u, F.err);
+            // ---- this thread group's column: X = xl + ((gcol - xl) mod fw), window column dx
+            int dx = (gcol - xl) % fw;
+            if (dx < 0) dx += fw;
+            const int X = xl + dx;
+            const bool col_in = X >= P.dx0 && X < P.dx1;     // inside the part's domain
+            const bool slide = held && held_y == cur.y && xl > held_xl && xl - held_xl < fw;
+            // with a slide, columns held_xl + fw .. xl + fw - 1 enter: dx >= fw - (xl - held_xl)
+            const bool enter = present && has_column && col_in && (!slide || dx >= fw - (xl - held_xl));
+            // the previous colour's update of column X comes from lattice column sx: the two
+            // spaxels (py0, sx), (py1, sx).  They are this slot's OWN previous spaxel (its G
+            // row is in LDS, no hand-off) or another slot's (flags, then sc1 loads).
+            const bool right = X - cur.px0 > fhw;
+            const int sx = right ? cur.px1 : cur.px0;
+            const bool sx_ok = have_pred && sx >= 0 && sx < P.W;
+            const int tapx = X - sx + fhw;
+            const bool own0 = sx == prev_x && cur.py0 == prev_y;
+            const bool own1 = sx == prev_x && cur.py1 == prev_y;
+            double2 gz0 = make_double2(0.0, 0.0), gz1 = gz0;
+            if (present && has_column && col_in && have_pred) {
+                const bool need0 = sx_ok && sy0_ok && (upd_rows & ((1u << min(max(rb, 0), FH)) - 1u));
+                const bool need1 = sx_ok && sy1_ok && (upd_rows >> min(max(rb, 0), FH));
+                const bool rem0 = (need0 || enter) && !own0, rem1 = (need1 || enter) && !own1;
+                // (1) residual stores of the slots that held this column's cells: flag1
+                // (one lane per thread group and per wavefront polls: every wavefront that
+                // loads handed-off bytes has seen the flags itself)
+                const bool poller = zl == 0 || lane == 0;
+                if (enter && (rem0 || rem1)) {
+                    if (poller && rem0) ok = chain_wait(F.flag1 + slot_of(cur.py0, sx), E - 1u, F.err);
+                    if (poller && rem1 && cur.py1 != cur.py0)
+                        ok = ok && chain_wait(F.flag1 + slot_of(cur.py1, sx), E - 1u, F.err);
+                }
+                // (2) their G rows: flag2, then this thread's z-pair of each (sc1)
+                if (poller && rem0 && need0) ok = ok && chain_wait(F.flag2 + slot_of(cur.py0, sx), E - 1u, F.err);
+                if (poller && rem1 && need1 && cur.py1 != cur.py0)
+                    ok = ok && chain_wait(F.flag2 + slot_of(cur.py1, sx), E - 1u, F.err);
                 ok = __all(ok);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // keep the loads below the polls
                 const double *Gp = F.G + ((size_t)cur.pring * F.K + cur.pk) * slots * Dp;
-                for (int i = tid; i < 4 * Dp; i += NS) {
-                    const int qd = i / Dp, z = i - qd * Dp;
-                    // (a lattice point outside the cube is no spaxel: no update, mh_ws_preds)
-                    const int sy = (qd & 2) ? cur.I.psy1[0] : cur.I.psy0[0];
-                    const int sx = (qd & 1) ? cur.I.psx1[0] : cur.I.psx0[0];
-                    double gv = 0.0;
-                    if (sy >= 0 && sx >= 0)
-                        gv = __longlong_as_double((long long)__hip_atomic_load(
-                            reinterpret_cast<const unsigned long long *>(
-                                Gp + (size_t)slot_of(sy, sx) * Dp + z),
-                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                    S.gp[i] = gv;
+                auto load_row = [&](int sy) {
+                    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
+                        Gp + (size_t)slot_of(sy, sx) * Dp + 2 * zl);
+                    double2 g2;
+                    g2.x = __longlong_as_double((long long)__hip_atomic_load(src, __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_AGENT));
+                    g2.y = __longlong_as_double((long long)__hip_atomic_load(src + 1, __ATOMIC_RELAXED,
+                                                                             __HIP_MEMORY_SCOPE_AGENT));
+                    return g2;
+                };
+                if (need0) gz0 = own0 ? *reinterpret_cast<const double2 *>(S.G + 2 * zl) : load_row(cur.py0);
+                if (need1) gz1 = own1 ? *reinterpret_cast<const double2 *>(S.G + 2 * zl) : load_row(cur.py1);
+            }
+            // the columns that enter the window (rows outside the domain: zeros)
+            if (enter) {
+#pragma unroll
+                for (int r = 0; r < FH; ++r) {
+                    if ((in_rows >> r) & 1u) {
+                        const long idx = ((long)(yt + r) * P.W + X) * Dp + 2 * zl;
+                        cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
+                        e[r] = cv.d;
+                        if (!UV) v[r] = *reinterpret_cast<const double2 *>(P.ivar + idx);
+                    } else {
+                        e[r] = make_double2(0.0, 0.0);
+                    }
                 }
             }
+            held = present;
+            held_xl = xl;
+            held_y = cur.y;
+#ifdef D3D_CHAIN_CLOCK
+            if (P.stamp && si == F.n_sweeps - 1 && tid == 0)
+                P.stamp[((long)blockIdx.x * F.K + k) * 8 + 1] = __builtin_amdgcn_s_memtime();
+#else
+            D3D_CHAIN_STAMP(1);
+#endif
             D3D_CHAIN_STAMP(2);
-            if (__syncthreads_or(!ok)) return;  // B0: G rows staged
-            // ---- (3) apply the pending layer, store, accumulate -- from registers
-            if (has_window && cur.present) {
+            D3D_CHAIN_STAMP(3);
+            // ---- (3) apply the pending layer in registers, accumulate; store what another
+            // workgroup reads next: the leaving columns -- or everything where the next colour
+            // reloads (a new row of colours, the window leaves the domain, a sweep or the
+            // launch ends).  S.fsf[npos] = 0: the tap of "no update here" / "row outside".
+            if (present && has_column && col_in) {
+                const int nxl = nxt.x - fhw;
+                const bool nslide = more && (nxt.flags & 1) && nxt.y == cur.y && nxl > xl && nxl - xl < fw;
+                const bool store_col = !nslide || dx < nxl - xl;
                 double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
 #pragma unroll
-                for (int i = 0; i < UT; ++i) {
-                    if (vox[i] < 0) continue;
-                    const int pw = g + i * G;
-                    const int p = cur.rev ? npos - 1 - pw : pw;
-                    const int code = cur.have_pred ? S.pos[2 * p + 1] : -1;
-                    if (code >= 0) {
-                        const double fp = S.fsf[code & 0xffff];
-                        const double2 gz = *reinterpret_cast<const double2 *>(
-                            S.gp + (size_t)(code >> 16) * Dp + 2 * zl);
-                        e[i].x = fma(fp, gz.x, e[i].x);
-                        e[i].y = fma(fp, gz.y, e[i].y);
-                        cv.d = e[i];
+                for (int r = 0; r < FH; ++r) {
+#ifdef D3D_EXPERIMENTS
+                    if (F.dbg & 1) continue;   // timing only: nothing per row
+#endif
+                    const bool in = (in_rows >> r) & 1u;
+                    const bool upd = ((upd_rows >> r) & 1u) && sx_ok;
+                    const int trow = (r >= rb) ? (yt + r - cur.py1 + fhh) : (yt + r - cur.py0 + fhh);
+                    const double fp = S.fsf[upd ? trow * fw + tapx : npos];
+                    const double2 gz = (r >= rb) ? gz1 : gz0;
+                    e[r].x = fma(fp, gz.x, e[r].x);
+                    e[r].y = fma(fp, gz.y, e[r].y);
+#ifdef D3D_EXPERIMENTS
+                    if (F.dbg & 2) continue;   // timing only: no stores, no sums
+#endif
+                    if (in && store_col) {
+                        cv.d = e[r];
                         __builtin_amdgcn_raw_buffer_store_b128(
-                            cv.i, err_rsrc, (int)(((long)vox[i] * Dp + 2 * zl) * 8), 0, 16);
+                            cv.i, err_rsrc, (int)((((long)(yt + r) * P.W + X) * Dp + 2 * zl) * 8), 0, 16);
                     }
-                    const double f = S.fsf[p];
-                    D3D_ACCUM(e[i], v[i], f);
+#ifdef D3D_EXPERIMENTS
+                    if (F.dbg & 4) continue;   // timing only: no sums
+#endif
+                    const double f = S.fsf[in ? r * fw + dx : npos];
+                    D3D_ACCUM(e[r], v[r], f);
                 }
-                if (cur.real) {
-                    double *r = S.red + (size_t)g * 3 * Dp + 2 * zl;
-                    r[0] = sA.x;
-                    r[1] = sA.y;
-                    r[Dp] = sB.x;
-                    r[Dp + 1] = sB.y;
-                    r[2 * Dp] = sC.x;
-                    r[2 * Dp + 1] = sC.y;
+                if (real) {  // partial sums of window column dx
+                    double *rr = S.red + (size_t)dx * 3 * Dp + 2 * zl;
+                    rr[0] = sA.x;
+                    rr[1] = sA.y;
+                    rr[Dp] = sB.x;
+                    rr[Dp + 1] = sB.y;
+                    rr[2 * Dp] = sC.x;
+                    rr[2 * Dp + 1] = sC.y;
                 }
+            } else if (present && has_column && real) {  // a column outside the domain: no terms
+                double *rr = S.red + (size_t)dx * 3 * Dp + 2 * zl;
+                rr[0] = rr[1] = rr[Dp] = rr[Dp + 1] = rr[2 * Dp] = rr[2 * Dp + 1] = 0.0;
             }
-            __syncthreads();  // B1: group partial sums are in S.red
-            D3D_CHAIN_STAMP(3);
-            MHProposal q = {};
-            double EO = 0.0, EN = 0.0;
-            if (cur.real) {
-                q = sprop[k];
-                if (streamer) {
-                    if (tid < Dp) {
-                        EO = S.G[tid];
-                        EN = sEN[tid];
-                    }
-                    mh_channel_sums(P, S, q, tid, G, EO, EN, 0);
-                }
-            }
-            __syncthreads();  // B2: the wave sums are in S.sum
             D3D_CHAIN_STAMP(4);
+            if (__syncthreads_or(!ok)) return;  // B1: column partial sums are in S.red (or a wait timed out)
+            D3D_CHAIN_STAMP(5);
+            // (the wavefronts that hold channels; the decision adds up their sums only)
+            if (real && tid < nstore * 64) mh_channel_sums(P, S, sprop[k], tid, fw, EO, EN, 0);
+            __syncthreads();  // B2: the wave sums are in S.sum
+            D3D_CHAIN_STAMP(6);
             // ---- (4) the extra wavefront decides; meanwhile the streaming wavefronts drain
-            // their residual stores (flag1) and build the next colour's table and lines
-            const bool more = k + 1 < F.K;
-            Geo nxt = cur;
-            if (more) nxt = geometry(si, k + 1);
+            // their residual stores (flag1) and fetch the next colour's lines
+            double EOn = 0.0, ENn = 0.0;
             if (!streamer) {
-                if (cur.real) {
+#ifdef D3D_EXPERIMENTS
+                if (real && !(F.dbg & 8)) {   // (8: timing only, no decision)
+#else
+                if (real) {
+#endif
+                    const MHProposal q = sprop[k];
                     const U2 u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
-                    mh_decide_wave(P, S, q, sp, sweep, NW, u_gibbs);
+                    mh_decide_wave(P, S, q, cur.y * P.W + cur.x, sweep, nstore, u_gibbs);
                     if (lane == 0) {  // the state the next sweep's proposal starts from
-                        const double *verdict = S.sum + 8 * NW;
+                        const double *verdict = S.sum + 8 * nstore;
                         const bool accept = verdict[0] != 0.0;
                         snew[3 * k + 0] = verdict[1];
                         snew[3 * k + 1] = accept ? q.pn[1] : q.c_old;
@@ -2951,28 +3075,37 @@ __global__ __launch_bounds__(NS + 64) void k_mh_chain(MHArgs P, MHChain F) {
                         __hip_atomic_store(F.flag1 + slot, E, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
-                if (more) {
-                    if (wave == 0 || NW == 1) build_lines(nxt, k + 1);
-                    if (NW > 1 && wave >= 1) build_table(nxt, 64, NS - 64);
-                    if (NW == 1) build_table(nxt, 0, NS);
+                if (more && (nxt.flags & 2) && tid < Dp) {
+                    const double *ln = lines + (size_t)(k + 1) * 2 * Dp;
+                    EOn = __longlong_as_double((long long)__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(ln + tid), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
+                    ENn = __longlong_as_double((long long)__hip_atomic_load(
+                        reinterpret_cast<const unsigned long long *>(ln + Dp + tid), __ATOMIC_RELAXED,
+                        __HIP_MEMORY_SCOPE_AGENT));
                 }
             }
-            __syncthreads();  // B3: verdict; next colour's table and lines
-            D3D_CHAIN_STAMP(5);
-            // ---- (5) publish the G row
+            __syncthreads();  // B3: the verdict
+            D3D_CHAIN_STAMP(7);
+            // ---- (5) the G row: into LDS for this slot's own next window, and published
             if (tid < nstore * 64) {
-                if (cur.present && tid < Dp) {
-                    const double Gt = cur.real ? mh_update_coeff(P, S, q, tid, EO, EN, NW) : 0.0;
-                    double *dst = F.G + (((size_t)(si & 1) * F.K + k) * slots + slot) * Dp + tid;
-                    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst),
-                                       (unsigned long long)__double_as_longlong(Gt), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    // the pending layer this launch leaves, where flush_pending and the next
-                    // launch look for it (in-cube lattice points only, as mh_ws_zero_row)
-                    if (!more && si == F.n_sweeps - 1 && cur.y >= 0 && cur.y < P.H && cur.x >= 0 &&
-                        cur.x < P.W)
-                        F.Gout[((long)(cur.y / fh) * P.slots_x + cur.x / fw) * Dp + tid] = Gt;
+                if (tid < Dp) {
+                    const double Gt = real ? mh_update_coeff(P, S, sprop[k], tid, EO, EN, nstore) : 0.0;
+                    S.G[tid] = Gt;
+                    if (present) {
+                        double *dst = F.G + (((size_t)(si & 1) * F.K + k) * slots + slot) * Dp + tid;
+                        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst),
+                                           (unsigned long long)__double_as_longlong(Gt), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        // the pending layer this launch leaves, where flush_pending and the next
+                        // launch look for it (in-cube lattice points only, as mh_ws_zero_row)
+                        if (last && cur.y >= 0 && cur.y < P.H && cur.x >= 0 && cur.x < P.W)
+                            F.Gout[((long)(cur.y / fh) * P.slots_x + cur.x / fw) * Dp + tid] = Gt;
+                    }
                 }
+            }
+            __syncthreads();  // B4: this slot's own G row is in LDS
+            if (tid < nstore * 64) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) {
                     const unsigned old = __hip_atomic_fetch_add(&sctl[1], 1u, __ATOMIC_RELAXED,
@@ -2983,8 +3116,11 @@ __global__ __launch_bounds__(NS + 64) void k_mh_chain(MHArgs P, MHChain F) {
                     }
                 }
             }
-            D3D_CHAIN_STAMP(6);
+            prev_y = cur.y;
+            prev_x = cur.x;
             cur = nxt;
+            EO = EOn;
+            EN = ENn;
         }
     }
 }

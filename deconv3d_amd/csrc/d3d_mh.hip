@@ -180,7 +180,8 @@ int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
 // family follows the part, not the context: a small part and a chip-filling part of one
 // context take different ones.
 template <bool UV>
-int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
+                 bool wide) {
     // (the uniform-variance variant also gains from the deeper queue at full size:
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
@@ -228,9 +229,9 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // bit with another scheme: a given part always takes the same form, so a tiled chain and
     // the single context given the same parts still agree to the last bit.  Shallow cubes lose
     // (32 channels: 9.9 -> 12.2 us per launch).  D3D_MH_WIDE=0: off.
-    if (small && c->mh_wide && (c->tiled || !c->part_rects.empty()) && c->Dp == 128 &&
-        grid <= (unsigned)c->flow_grid / 4)
-        return launch_mh_ws_um<UV, 1, 1, 1, false, 960>(c, P, grid, sweep);
+    // (decided per PART, Part::wide, so that every colour of a part -- and the chain kernel
+    // that replaces its launches -- groups the window sums alike)
+    if (small && wide) return launch_mh_ws_um<UV, 1, 1, 1, false, MH_WIDE_NS>(c, P, grid, sweep);
     if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
 }
@@ -337,13 +338,14 @@ int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
 }
 #endif  // D3D_EXPERIMENTS
 
-int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
+                    bool wide) {
     // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
     // tail, so D <= 256) + one prepare wavefront
     if (c->mh_defer == 1 && c->Dp <= 256) {
         if (c->ivar_is_uniform && c->uniform_fast_path)
-            return launch_mh_ws<true>(c, P, grid, sweep, layers);
-        return launch_mh_ws<false>(c, P, grid, sweep, layers);
+            return launch_mh_ws<true>(c, P, grid, sweep, layers, wide);
+        return launch_mh_ws<false>(c, P, grid, sweep, layers, wide);
     }
     switch (c->mh_nt) {
         case 128: return launch_mh_defer_nt<128>(c, P, grid, sweep);
@@ -376,6 +378,106 @@ int flush_pending(d3d_ctx *c) {
     return 0;
 }
 
+
+// ---- k_mh_chain: whole sweeps of a small part in one launch --------------------------------
+namespace {
+// Chain kernels of different contexts of one process must not share the chip: each needs
+// ALL its workgroups resident (they wait for each other), and two half-resident grids would
+// wait forever (until the kernels' time-out).  One event per device orders them.
+hipEvent_t g_chain_done[64] = {};
+bool g_chain_recorded[64] = {};
+
+template <int FH, bool UV>
+int launch_mh_chain_t(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHChain &F, int slots) {
+    auto kern = d3d::k_mh_chain<FH, UV, MH_CHAIN_NT>;
+    const int nw = (F.NS + 63) / 64;
+    // one workgroup per CU (the hand-off forms are measured for that): ask for more than
+    // half of the 160 KiB of LDS
+    size_t lds = d3d::mh_chain_lds_doubles(c->fw, c->Dp, c->N, P.npos, F.K, nw) * sizeof(double);
+    lds = std::max(lds, (size_t)82 * 1024);
+    if (lds > (size_t)160 * 1024) return fail(D3D_ERR_STATE, "internal: chain kernel needs %zu B of LDS", lds);
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)slots), dim3(nw * 64 + 64), lds, c->stream, P, F);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int FH>
+int launch_mh_chain_uv(d3d_ctx *c, const d3d::MHArgs &P, const d3d::MHChain &F, int slots) {
+    if (c->ivar_is_uniform && c->uniform_fast_path) return launch_mh_chain_t<FH, true>(c, P, F, slots);
+    return launch_mh_chain_t<FH, false>(c, P, F, slots);
+}
+}  // namespace
+
+int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps) {
+    d3d_ctx::Part &pt = c->parts[pi];
+    if (!pt.chain || n_sweeps <= 0) return fail(D3D_ERR_STATE, "internal: part %d has no chain form", pi);
+    if (c->lay_n)  // the kernel starts from a residual with nothing pending
+        if (int rc = flush_pending(c)) return rc;
+    const int slots = pt.n_sy * pt.n_sx;
+    const int fhh = (c->fh - 1) / 2;
+    // epochs are 32-bit and monotonic over launches: start over long before they wrap
+    const unsigned span = (unsigned)n_sweeps * (unsigned)pt.K;
+    if (c->chain_base > (1u << 30) || c->chain_base + span < c->chain_base) {
+        HIP_TRY(hipMemsetAsync(c->chain_flags, 0, 2 * c->chain_slots_cap * sizeof(unsigned), c->stream));
+        c->chain_base = 0;
+    }
+    c->pend_part = pi;  // fill_mh_args takes the domain from it
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const int g_out = pend_free_buf(c);
+    d3d::MHChain F;
+    F.cols = c->chain_cols + (size_t)pi * c->fh * c->fw;
+    F.flag1 = c->chain_flags;
+    F.flag2 = c->chain_flags + c->chain_slots_cap;
+    F.err = c->flow_err;
+    F.G = c->chain_G;
+    F.Gout = c->gbuf[g_out];
+    F.lines = c->chain_G + (size_t)2 * pt.K * slots * c->Dp;
+    F.dbg = 0;
+#ifdef D3D_EXPERIMENTS
+    if (const char *e = getenv("D3D_CHAIN_DBG")) F.dbg = atoi(e);  // timing-only switches (wrong results)
+#endif
+    F.K = pt.K;
+    F.n_sy = pt.n_sy;
+    F.n_sx = pt.n_sx;
+    F.sy0 = pt.dy0 - fhh;
+    F.sx0 = pt.chain_sx0;
+    F.py0 = pt.y0;
+    F.py1 = pt.y1;
+    F.px0 = pt.x0;
+    F.px1 = pt.x1;
+    F.base = c->chain_base;
+    F.sweep0 = sweep0;
+    F.n_sweeps = n_sweeps;
+    F.NS = pt.chain_ns;
+#ifdef D3D_EXPERIMENTS
+    if (c->stampbuf && (size_t)slots * pt.K * 8 <= c->stamp_launches * c->stamp_stride) P.stamp = c->stampbuf;
+#endif
+    const int dev = c->device & 63;
+    if (!g_chain_done[dev]) HIP_TRY(hipEventCreateWithFlags(&g_chain_done[dev], hipEventDisableTiming));
+    if (g_chain_recorded[dev]) HIP_TRY(hipStreamWaitEvent(c->stream, g_chain_done[dev], 0));
+    int rc;
+    switch (c->fh) {
+        case 3: rc = launch_mh_chain_uv<3>(c, P, F, slots); break;
+        case 5: rc = launch_mh_chain_uv<5>(c, P, F, slots); break;
+        case 7: rc = launch_mh_chain_uv<7>(c, P, F, slots); break;
+        case 9: rc = launch_mh_chain_uv<9>(c, P, F, slots); break;
+        default: rc = launch_mh_chain_uv<11>(c, P, F, slots); break;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(g_chain_done[dev], c->stream));
+    g_chain_recorded[dev] = true;
+    c->chain_base += span;
+    c->chain_used = true;
+    // afterwards the part's last colour is the one pending layer (local residues)
+    pend_clear(c);
+    pend_push(c, ((pt.last_col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
+              ((pt.last_col % c->fw - c->gx0) % c->fw + c->fw) % c->fw, g_out);
+    c->pend_part = pi;
+    return 0;
+}
 
 int launch_apply_updates(d3d_ctx *c, const d3d::MHArgs &P, const double *rec, int n) {
     const size_t lds = (size_t)(2 * c->N + c->Dp) * sizeof(double);

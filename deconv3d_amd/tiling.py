@@ -221,7 +221,7 @@ def setup_tile_engine(engine, layout, rank):
 
 
 def make_tile_engine(layout, rank, data, var, mask, fsf, lsf, params, min_b, max_b,
-                     jump_amplitude, ra, seed, device=0, err=None, refresh_every=0):
+                     jump_amplitude, ra, seed, device=0, err=None, refresh_every=0, options=None):
     """`_lib.Engine` holding rank's region of the global problem.  The initial
     residual is rebuilt from the region's own parameters (exact on the used cells);
     `err`, a GLOBAL residual cube, overrides it (the bit-identity tests hand every
@@ -230,7 +230,7 @@ def make_tile_engine(layout, rank, data, var, mask, fsf, lsf, params, min_b, max
     ry0, ry1, rx0, rx1 = layout.region(rank)
     oy0, oy1, ox0, ox1 = layout.owned(rank)
     D = data.shape[0]
-    eng = _lib.Engine((D, ry1 - ry0, rx1 - rx0), fsf.shape, device=device)
+    eng = _lib.Engine((D, ry1 - ry0, rx1 - rx0), fsf.shape, device=device, options=options)
     eng.set_taps(fsf, lsf)
     eng.set_tile(ry0, rx0, layout.W, oy0 - ry0, oy1 - ry0, ox0 - rx0, ox1 - rx0)
     sub = (slice(None), slice(ry0, ry1), slice(rx0, rx1))
