@@ -55,6 +55,9 @@ WORKLOADS = {
     "c3_300x300x128": (128, 300, 300, 11),
     "c2_64x64x64": (64, 64, 64, 11),
     "c1_32x16x16": (32, 16, 16, 9),
+    # config 3's footprint and taps at other depths (the convolution kernels' other forms)
+    "d64_300x300x64": (64, 300, 300, 11),
+    "d256_300x300x256": (256, 300, 300, 11),
 }
 
 
@@ -269,7 +272,15 @@ def finish_tiled_leg(leg, rank):
                 continue
             return {"value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
                     "n_gpus": rec["n_gpus"], "steps": rec["steps"], "scaling": "strong",
-                    "acceptance": rec.get("acceptance"), "config": rec["config"]}
+                    "acceptance": rec.get("acceptance"), "config": rec["config"],
+                    # the run checks itself (tiling.bench_tiled): gathered parameters against
+                    # one context given the same parts, on rank 0
+                    "bit_identical": rec.get("bit_identical"),
+                    "max_abs_param_diff": rec.get("max_abs_param_diff"), "tiles": rec.get("tiles"),
+                    "phases_per_sweep": rec.get("phases_per_sweep"),
+                    "rccl_ranks": rec.get("rccl_ranks"),
+                    "halo_ms_per_sweep": rec.get("halo_ms_per_sweep"),
+                    "verified_against": rec.get("verified_against")}
     errf.seek(0)
     tail = errf.read().decode(errors="replace").strip().splitlines()[-3:]
     return {"error": "tiled leg exited with code %s" % proc.returncode, "stderr_tail": tail}
@@ -278,8 +289,11 @@ def finish_tiled_leg(leg, rank):
 def measured_traffic(kernel_prefix, workload):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
-    [gfx950 correction] + WRITE_SIZE KiB, separate passes); None if the profile
-    on record is for another workload."""
+    [gfx950 correction] + WRITE_SIZE KiB, separate passes).  None if no profile on
+    record is for this workload; the string "stale" if the newest one was taken with
+    another build of the library than the one loaded now (the JSON carries
+    d3d_source_hash()): a traffic figure only counts for the kernels it was measured on."""
+    from deconv3d_amd import _lib
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if not os.path.isdir(pdir):
@@ -295,8 +309,15 @@ def measured_traffic(kernel_prefix, workload):
             continue
         for k, v in rec.get("hbm_bytes_per_launch", {}).items():
             if k.split("::")[-1].startswith(kernel_prefix):
-                best = int(v)
+                best = int(v) if rec.get("source_hash") == _lib.source_hash() else "stale"
     return best
+
+
+def traffic_rates(entry, us):
+    """traffic_gbs / traffic_frac of a roofline entry whose `traffic` is a byte count."""
+    if isinstance(entry.get("traffic"), int) and entry["traffic"] > 0:
+        entry["traffic_gbs"] = round(entry["traffic"] / (us * 1e-6) / 1e9, 1)
+        entry["traffic_frac"] = round(entry["traffic_gbs"] / HBM_PEAK_GBS, 4)
 
 
 def beyond_mall_leg(args, local_rank, fs):
@@ -333,6 +354,34 @@ def beyond_mall_leg(args, local_rank, fs):
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
                 "launches": ncol * steps, "residual_written_every": eng.mh_layers(),
                 "value": round(steps * H * W / (ms * 1e-3), 1), "unit_value": "spaxel-updates/s"}
+
+
+def conv_beyond_mall_leg(args, local_rank, fs):
+    """The one-pass convolution on a 600x600x128 cube: 369 MB in + 369 MB out, beyond the
+    256 MB Infinity Cache that can hold most of the headline cube's 92 + 92 MB."""
+    from deconv3d_amd import _lib
+    D, H, W = 128, 600, 600
+    fsf, lsf = build_taps(D, fs)
+    iters = max(5, min(args.conv_iters, 20))
+    rng = np.random.default_rng(5)
+    with _lib.Engine((D, H, W), fsf.shape, device=local_rank) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.upload_slot(_lib.SLOT_DATA, rng.normal(size=(D, H, W)))
+        eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
+        eng.sync()
+        eng.timer_start()
+        for _ in range(iters):
+            eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
+        ms = eng.timer_stop() / iters
+    nbytes = 2 * 8 * D * H * W
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    ntaps = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
+    flops = 2.0 * (fsf.size + ntaps) * D * H * W
+    return {"kernel": "k_conv_rows, 600x600x128 cube (369 MB in + 369 MB out > 256 MB MALL)",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": nbytes,
+            "ms_per_conv": round(ms, 4), "fp64_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+            "fp64_frac": round(flops / (ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)}
 
 
 def main():
@@ -496,11 +545,9 @@ def main():
                 # every `residual_written_every` colours and applies the pending updates
                 # in registers in between, which is why `traffic` is lower
                 "residual_written_every": eng.mh_layers()}
-    if roofline["traffic"]:
-        # HBM bytes the counters saw per launch / the same launch time (the
-        # kernel moves fewer bytes than the algorithmic 24 B per window voxel)
-        roofline["traffic_gbs"] = round(roofline["traffic"] / (avg_launch_us * 1e-6) / 1e9, 1)
-        roofline["traffic_frac"] = round(roofline["traffic_gbs"] / HBM_PEAK_GBS, 4)
+    # HBM bytes the counters saw per launch / the same launch time (the
+    # kernel moves fewer bytes than the algorithmic 24 B per window voxel)
+    traffic_rates(roofline, avg_launch_us)
 
     # ---- separable convolution roofline (north_star's second target) ---------
     # cube in -> cube out, device resident.  (a) in the reference's own (D,H,W)
@@ -555,6 +602,9 @@ def main():
         "config": {"workload": args.workload, "cube": [D, H, W], "fsf": "moffat %dx%d" % (fh, fw)
                    if fs != 9 else "gaussian 9x9",
                    "lsf_taps": ntaps_lsf, "spaxels": n_spaxels,
+                   # BASELINE config 3 names MUSELineSpreadFunction: the reference delegates it
+                   # to mpdaf (absent here, unpinned), so the taps are the documented stand-in
+                   "lsf": "gaussian" if fs == 9 else "analytic MUSE stand-in (mpdaf absent)",
                    "parallelism": "1 chain" if world == 1 else "ensemble of %d chains" % world,
                    "variance": "per-voxel cube (heteroscedastic)"},
         "acceptance": round(accepted / float(args.steps * n_spaxels), 4),
@@ -586,6 +636,7 @@ def main():
         out["host"] = host_info()
     if rank == 0 and not args.no_extras and args.workload == "c3_300x300x128":
         out["roofline_beyond_mall"] = beyond_mall_leg(args, local_rank, fs)
+        out["roofline_conv_beyond_mall"] = conv_beyond_mall_leg(args, local_rank, fs)
     if rank == 0 and not args.no_extras:
         # the reference's default variance (Run(variance=None): one constant,
         # lib/run.py:171-178): the MH kernel does not read SLOT_IVAR at all

@@ -31,7 +31,8 @@ SYMBOLS = [
     "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform", "d3d_mh_layers",
     "d3d_colour_count", "d3d_rtnorm",
     "d3d_set_tile", "d3d_set_parts", "d3d_mh_phase", "d3d_mh_accepted", "d3d_flush",
-    "d3d_halo_plan", "d3d_comm_unique_id", "d3d_comm_init", "d3d_comm_destroy",
+    "d3d_halo_plan", "d3d_comm_unique_id", "d3d_comm_init", "d3d_comm_destroy", "d3d_comm_info",
+    "d3d_halo_time",
     "d3d_halo_exchange", "d3d_halo_pack", "d3d_halo_unpack", "d3d_halo_buffers",
     "d3d_halo_download", "d3d_halo_upload", "d3d_device_copy",
     "d3d_mh_colour", "d3d_export_updates", "d3d_apply_updates",
@@ -126,6 +127,8 @@ def load():
     lib.d3d_comm_unique_id.argtypes = [C.c_void_p]
     lib.d3d_comm_init.argtypes = [ctx_p, C.c_int, C.c_int, C.c_void_p]
     lib.d3d_comm_destroy.argtypes = [ctx_p]
+    lib.d3d_comm_info.argtypes = [ctx_p, int_p, int_p]
+    lib.d3d_halo_time.argtypes = [ctx_p, dbl_p, C.POINTER(C.c_long), C.c_int]
     lib.d3d_halo_exchange.argtypes = [ctx_p, C.c_int]
     lib.d3d_halo_pack.argtypes = [ctx_p, C.c_int]
     lib.d3d_halo_unpack.argtypes = [ctx_p, C.c_int]
@@ -477,6 +480,19 @@ class Engine(object):
 
     def comm_destroy(self):
         _check(self._lib.d3d_comm_destroy(self._ctx))
+
+    def comm_info(self):
+        """(ranks RCCL says joined the communicator, this rank as RCCL numbers it)."""
+        n, r = C.c_int(0), C.c_int(0)
+        _check(self._lib.d3d_comm_info(self._ctx, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def halo_time(self, reset=False):
+        """(milliseconds, exchanges) of the halo exchanges d3d_mh_sweeps ran since the last
+        reset (needs option halo_timing = 1)."""
+        ms, n = C.c_double(0.), C.c_long(0)
+        _check(self._lib.d3d_halo_time(self._ctx, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
 
     def halo_exchange(self, plan):
         _check(self._lib.d3d_halo_exchange(self._ctx, int(plan)))

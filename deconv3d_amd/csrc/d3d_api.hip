@@ -40,6 +40,8 @@ struct RcclApi {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -396,6 +398,8 @@ const OptDesc g_opts[] = {
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
     {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
+    {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 40},
+    {"halo_timing", "D3D_HALO_TIMING", &d3d_ctx::halo_timing, OPT_LAUNCH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
     {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
     {"mh_nt", "D3D_MH_NT", &d3d_ctx::mh_nt_opt, OPT_MH, 0, 1024},
@@ -604,6 +608,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->halo_send) (void)hipFree(c->halo_send);
     if (c->halo_recv) (void)hipFree(c->halo_recv);
+    for (hipEvent_t e : c->halo_ev) (void)hipEventDestroy(e);
     for (int s = 0; s < D3D_SLOT_COUNT; ++s)
         if (c->slot[s]) (void)hipFree(c->slot[s]);
     void *ptrs[] = {c->stage, c->stage2, c->params, c->params_alt, c->mask, c->fsf, c->lsf_shift, c->lsf_weight,
@@ -1356,8 +1361,23 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                 int rc = run_phase(c, ph, rs);
                 if (rc) return rc;
                 if (plan_has_entries(c, ph)) {
+                    hipEvent_t ev[2] = {nullptr, nullptr};
+                    if (c->halo_timing) {
+                        if (c->halo_ev_used + 2 > c->halo_ev.size()) {
+                            for (int k = 0; k < 2; ++k) {
+                                hipEvent_t e;
+                                HIP_TRY(hipEventCreate(&e));
+                                c->halo_ev.push_back(e);
+                            }
+                        }
+                        ev[0] = c->halo_ev[c->halo_ev_used];
+                        ev[1] = c->halo_ev[c->halo_ev_used + 1];
+                        c->halo_ev_used += 2;
+                        HIP_TRY(hipEventRecord(ev[0], c->stream));
+                    }
                     rc = halo_exchange(c, ph);
                     if (rc) return rc;
+                    if (ev[1]) HIP_TRY(hipEventRecord(ev[1], c->stream));
                 }
             }
         }
@@ -1388,6 +1408,13 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     while (snaps.count > 0)
         if (int rc = snap_drain_one(c, snaps, chain_out, dlog_out)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i + 1 < c->halo_ev_used; i += 2) {  // option halo_timing
+        float f = 0.f;
+        HIP_TRY(hipEventElapsedTime(&f, c->halo_ev[i], c->halo_ev[i + 1]));
+        c->halo_ms += (double)f;
+        ++c->halo_count;
+    }
+    c->halo_ev_used = 0;
     if (accepted) *accepted = (int64_t)acc;
     c->chain_used = false;
     NEED(!flow_err, D3D_ERR_HIP,
@@ -1690,6 +1717,8 @@ int load_rccl() {
     D3D_SYM(Recv, "ncclRecv");
     D3D_SYM(GroupStart, "ncclGroupStart");
     D3D_SYM(GroupEnd, "ncclGroupEnd");
+    D3D_SYM(CommCount, "ncclCommCount");
+    D3D_SYM(CommUserRank, "ncclCommUserRank");
     D3D_SYM(GetErrorString, "ncclGetErrorString");
 #undef D3D_SYM
     g_rccl = a;
@@ -1913,6 +1942,25 @@ int d3d_comm_destroy(d3d_ctx *c) {
     ncclComm_t comm = c->comm;
     c->comm = nullptr;
     RCCL_TRY(g_rccl.CommDestroy(comm));
+    return D3D_OK;
+}
+
+int d3d_halo_time(d3d_ctx *c, double *ms, long *count, int reset) {
+    NEED(c && ms, D3D_ERR_INVALID, "NULL argument");
+    *ms = c->halo_ms;
+    if (count) *count = c->halo_count;
+    if (reset) {
+        c->halo_ms = 0.0;
+        c->halo_count = 0;
+    }
+    return D3D_OK;
+}
+
+int d3d_comm_info(d3d_ctx *c, int *nranks, int *rank) {
+    NEED(c && nranks && rank, D3D_ERR_INVALID, "NULL argument");
+    NEED(c->comm, D3D_ERR_STATE, "d3d_comm_init has not been called");
+    RCCL_TRY(g_rccl.CommCount(c->comm, nranks));
+    RCCL_TRY(g_rccl.CommUserRank(c->comm, rank));
     return D3D_OK;
 }
 

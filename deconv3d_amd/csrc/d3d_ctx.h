@@ -117,6 +117,12 @@ struct d3d_ctx {
     // RCCL communicator of the tiled chain (d3d_comm_init)
     ncclComm_t comm = nullptr;
     int comm_rank = -1, comm_size = 0;
+    // option halo_timing = 1: HIP events around every halo exchange of d3d_mh_sweeps
+    int halo_timing = 0;
+    std::vector<hipEvent_t> halo_ev;   // pairs (start, stop), recorded on the ctx stream
+    size_t halo_ev_used = 0;
+    double halo_ms = 0.0;              // summed at the end of each d3d_mh_sweeps call
+    long halo_count = 0;
     std::vector<uint8_t> h_mask;
 
     bool have_taps = false, have_data = false, have_params = false, have_cfg = false;
@@ -167,6 +173,7 @@ struct d3d_ctx {
     size_t chain_G_cap = 0;
     unsigned chain_base = 0;       // the epoch every flag of a finished launch holds
     bool chain_used = false;       // a chain launch ran since the error word was last read
+    int mh_prio = 0;               // option mh_prio: staggered completion by wave priority (MHArgs::prio)
     int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)

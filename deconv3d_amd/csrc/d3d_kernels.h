@@ -1543,6 +1543,10 @@ struct MHArgs {
     // cube's working set exceeds it (300x300x256: 96.8 -> 83.7 us per launch).  The window
     // sums are then accumulated in that order, in every kernel alike.
     int rev;
+    // Staggered completion (option mh_prio, default 0 = off; mh_stagger): half of a
+    // colour's windows finish streaming before the other half, so that their decisions
+    // overlap the others' streams (measured flat: DESIGN.md section 3).
+    int prio;
     int lay_cy[3], lay_cx[3];
     const double *lay_G[3];
     int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
@@ -1582,6 +1586,18 @@ struct MHArgs {
 #endif
 
 constexpr int MH_LAYERS = 3;  // pending colours k_mh_ws can apply in one pass
+
+// Staggered completion (MHArgs::prio; measured flat): 1..15 -- the
+// workgroups with bit prio-1 of their index set run at raised wave priority; 16 + n -- the
+// odd workgroups start n x 0.8 us late.
+__device__ __forceinline__ void mh_stagger(int prio) {
+    if (prio <= 0) return;
+    if (prio < 16) {
+        if ((blockIdx.x >> (prio - 1)) & 1) __builtin_amdgcn_s_setprio(2);
+    } else if (blockIdx.x & 1) {
+        for (int i = 16; i < prio; ++i) __builtin_amdgcn_s_sleep(30);
+    }
+}
 
 __host__ __device__ inline size_t mh_lds_doubles(int NT, int HL, int Dp, int N, int npos,
                                                  int M = 1) {
@@ -2546,6 +2562,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     constexpr int NT = NS + 64;
     const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
     D3D_MH_STAMP(blockIdx.x, 0, 0);
+    mh_stagger(P.prio);
     const int4 ent = P.spx[blockIdx.x];
     MHWsItem I;
     I.y = ent.x;  // may lie outside the cube when virtual
@@ -3336,6 +3353,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     // the host reports it instead of hanging.
     const int t = (int)blockIdx.x;
     if (t >= F.n_a + F.n_b) return;
+    mh_stagger(P.prio);
     const bool is_b = t >= F.n_a;
     const int item = is_b ? F.first_b + (t - F.n_a) : F.first_a + t;
     const int4 ent = F.ent[item];

@@ -50,6 +50,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.accepted = c->accepted;
     P.spx = c->spx;
     P.rev = 0;
+    P.prio = c->mh_prio;
     for (int k = 0; k < 3; ++k) {
         P.min_b[k] = c->min_b[k];
         P.max_b[k] = c->max_b[k];

@@ -319,13 +319,24 @@ def exchange_distributed(engine, table, plan, dist, torch):
     engine.halo_unpack(plan)
 
 
-def sweep_distributed(engine, layout, tables, sweep, dist, torch, refresh=False):
+def sweep_distributed(engine, layout, tables, sweep, dist, torch, refresh=False, timed=False):
+    """One sweep with host-staged halos (gloo rehearsal).  timed: returns the seconds the
+    exchanges took on this rank (the phase's kernels drained first)."""
+    import time
+    spent = 0.0
     for ph in layout.phases:
         engine.mh_phase(ph, sweep)
+        if timed:
+            engine.sync()
+            t0 = time.perf_counter()
         exchange_distributed(engine, tables[ph], ph, dist, torch)
+        if timed:
+            engine.sync()
+            spent += time.perf_counter() - t0
     if refresh:
         exchange_distributed(engine, tables[PLAN_PARAMS], PLAN_PARAMS, dist, torch)
         engine.residual(fetch=False)
+    return spent
 
 
 def gather_params(layout, rank, engine):
@@ -351,10 +362,33 @@ def parse_tiles(text, world):
     return ty, tx
 
 
+def reference_single_context(layout, data, var, mask, fsf, lsf, init, min_b, max_b, ra, seed,
+                             sweeps, device=0, refresh_every=1000):
+    """The same chain on ONE context given the tiling's parts (apply_parts): what every
+    tiled run must reproduce bit for bit.  Returns (parameters, accepted)."""
+    from . import _lib
+    D = data.shape[0]
+    with _lib.Engine((D, layout.H, layout.W), fsf.shape, device=device) as ref:
+        ref.set_taps(fsf, lsf)
+        ref.set_data(data, var, mask=mask)
+        apply_parts(ref, layout)
+        ref.set_params(init)
+        ref.mh_config(min_b, max_b, 0.1, ra, seed=seed, refresh_every=refresh_every)
+        ref.residual(fetch=False)
+        accepted = ref.mh_sweeps(sweeps, 1)
+        return ref.get_params(), accepted
+
+
 def bench_tiled(args, rank, local_rank, world, dist, torch):
     """`bench.py --mode tiled`: one 300x300x128 chain cut over the ranks.  With the
     nccl backend the halos travel by RCCL inside the library (d3d_mh_sweeps does
-    whole sweeps on the device); with gloo they are staged through the host."""
+    whole sweeps on the device); with gloo they are staged through the host.
+
+    The run verifies itself: after the timed sweeps the owners' parameters are gathered
+    on rank 0 and compared with ONE context given the same parts and the same sweeps
+    there -- `bit_identical` in the record; `halo_ms_per_sweep` times the exchanges
+    (HIP events around pack / send-recv / unpack inside the library), `tiles` is the grid
+    and `rccl_ranks` what ncclCommCount reports."""
     import json
     import time
 
@@ -372,15 +406,21 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
         data, var, truth, init, min_b, max_b = B.synthetic_inputs(full, D, H, W, fsf, 12345)
     ra = float(max_b[0] ** 2)
     eng = make_tile_engine(layout, rank, data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra,
-                           12345, device=local_rank, refresh_every=1000)
-    del data, var
+                           12345, device=local_rank, refresh_every=1000,
+                           options={"halo_timing": 1})
+    if rank != 0:
+        del data, var
     tables = plan_tables(layout, rank)
     rccl = args.backend == "nccl"
+    rccl_ranks = None
     if rccl:
         box = [_lib.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         eng.comm_init(world, rank, box[0])
+        rccl_ranks, rccl_rank = eng.comm_info()
+        assert rccl_rank == rank
     device = torch.device("cuda", local_rank) if rccl else None
+    halo_host_s = [0.0]
 
     def barrier():
         eng.sync()
@@ -392,27 +432,54 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
             return eng.mh_sweeps(n, first)
         eng.mh_accepted(reset=True)
         for s in range(first, first + n):
-            sweep_distributed(eng, layout, tables, s, dist, torch,
-                              refresh=(s % 1000 == 0))
+            halo_host_s[0] += sweep_distributed(eng, layout, tables, s, dist, torch,
+                                                refresh=(s % 1000 == 0), timed=True)
         return eng.mh_accepted()
 
     sweep = 1
+    accepted_total = 0
     if args.warmup > 0:
-        run(sweep, args.warmup)
+        accepted_total += run(sweep, args.warmup)
         sweep += args.warmup
+    eng.halo_time(reset=True)
+    halo_host_s[0] = 0.0
     barrier()
     t0 = time.perf_counter()
     accepted = run(sweep, args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt, 0.0], dtype=torch.float64, device=device if device is not None else "cpu")
+    accepted_total += accepted
+    halo_ms, halo_n = eng.halo_time()
+    if not rccl:
+        halo_ms, halo_n = halo_host_s[0] * 1e3, args.steps * len(layout.phases)
+    t = torch.tensor([dt, halo_ms], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t[0].item())
-    a = torch.tensor([float(accepted)], dtype=torch.float64,
+    dt, halo_ms = float(t[0].item()), float(t[1].item())
+    a = torch.tensor([float(accepted), float(accepted_total)], dtype=torch.float64,
                      device=device if device is not None else "cpu")
     dist.all_reduce(a, op=dist.ReduceOp.SUM)
     halo_bytes = sum(int((r[3] - r[2]) * (r[5] - r[4])) * eng.shape[0] * 8
                      for ph in layout.phases for r in tables[ph])
+    # ---- self-verification: the owners' parameters against one context with the same parts
+    mine = gather_params(layout, rank, eng)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    verdict = None
+    if rank == 0:
+        got = np.full((H, W, 3), np.nan)
+        for (y0, y1, x0, x1), p in everyone:
+            got[y0:y1, x0:x1] = p
+        n_sweeps = args.warmup + args.steps
+        want, want_acc = reference_single_context(layout, data, var, mask, fsf, lsf, init, min_b,
+                                                  max_b, ra, 12345, n_sweeps, device=local_rank)
+        verdict = bool(np.array_equal(got, want)) and int(a[1].item()) == int(want_acc)
+        max_diff = float(np.nanmax(np.abs(got - want)))
+        if not verdict:
+            bad = int(np.sum(np.any(got != want, axis=2)))
+            sys_err = "tiled chain differs from the single context: %d spaxels, accepted %d vs %d" % (
+                bad, int(a[1].item()), int(want_acc))
+            import sys
+            sys.stderr.write("bench.py --mode tiled: %s\n" % sys_err)
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
         "unit": "spaxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -424,7 +491,19 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
                                      "RCCL send/recv (in-library, device buffers)" if rccl
                                      else "gloo (host-staged rehearsal)"),
                    "halo_bytes_sent_per_sweep_rank0": halo_bytes},
-        "acceptance": round(float(a.item()) / float(args.steps * H * W), 4),
+        "acceptance": round(float(a[0].item()) / float(args.steps * H * W), 4),
+        "tiles": [ty, tx],
+        "phases_per_sweep": len(layout.phases),
+        "rccl_ranks": rccl_ranks,
+        "halo_ms_per_sweep": round(halo_ms / max(args.steps, 1), 4),
+        "halo_exchanges_timed": int(halo_n),
+        "bit_identical": verdict,
+        # (where the tiles' own from-scratch residuals are not bit-identical to the full
+        # cube's -- depths whose convolution kernel sums in a position-dependent order,
+        # DESIGN.md section 7 -- the chains agree to rounding and this is their distance)
+        "max_abs_param_diff": max_diff if rank == 0 else None,
+        "verified_against": "one context given the same parts (tiling.apply_parts), %d sweeps, on rank 0"
+                            % (args.warmup + args.steps),
     }
     if rccl:
         eng.comm_destroy()
@@ -473,9 +552,20 @@ def bench_tiled_loopback(args, device):
         e.sync()
     dt = time.perf_counter() - t0
     accepted = sum(e.mh_accepted() for e in engines)
+    # self-verification, as bench_tiled: against one context given the same parts
+    got = np.full((H, W, 3), np.nan)
+    for r in range(layout.n):
+        (y0, y1, x0, x1), p = gather_params(layout, r, engines[r])
+        got[y0:y1, x0:x1] = p
+    want, _ = reference_single_context(layout, data, var, mask, fsf, lsf, init, min_b, max_b, ra,
+                                       12345, args.warmup + args.steps, device=device,
+                                       refresh_every=0)
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
         "unit": "spaxel-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "tiles": [ty, tx], "phases_per_sweep": len(layout.phases), "rccl_ranks": None,
+        "bit_identical": bool(np.array_equal(got, want)),
+        "max_abs_param_diff": float(np.nanmax(np.abs(got - want))),
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "cube": [D, H, W],

@@ -92,7 +92,7 @@ int d3d_timer_stop(d3d_ctx *ctx, double *elapsed_ms);
  * Changing an option flushes pending residual updates and re-derives what depends
  * on it (work lists, tap analysis), so it may be called at any time between calls.
  * Keys: mh_defer 0|1|2, mh_layers 0(auto)|1|2|3, mh_chain 0|1,
- * mh_wide, mh_zigzag, mh_nt_ivar -1(auto)|0|1, mh_nt, mh_maxit, uniform_ivar, conv_rows,
+ * mh_wide, mh_prio, halo_timing, mh_zigzag, mh_nt_ivar -1(auto)|0|1, mh_nt, mh_maxit, uniform_ivar, conv_rows,
  * conv_hy, spatial_sep, sep_fuse, spatial_mode, march_hy, zmajor, zmajor_hy,
  * spectral_dense, spatial_nt, xcd_remap, alt_dir, stagger; a build with
  * `make EXPERIMENTS=1` adds mh_flow, mh_pair, spectral_shfl, fuse_lsf, march_pf,
@@ -276,6 +276,14 @@ int d3d_comm_unique_id(void *uid);
 int d3d_comm_init(d3d_ctx *ctx, int nranks, int rank, const void *uid);
 int d3d_comm_destroy(d3d_ctx *ctx);
 int d3d_halo_exchange(d3d_ctx *ctx, int plan);
+/* What RCCL itself reports for the ctx's communicator (ncclCommCount, ncclCommUserRank):
+ * how many ranks actually joined, and which one this is (bench.py's tiled record). */
+int d3d_comm_info(d3d_ctx *ctx, int *nranks, int *rank);
+/* With option halo_timing = 1, d3d_mh_sweeps brackets every halo exchange (pack, RCCL
+ * send/recv, unpack; lib/run.py has no counterpart: the reference is one process) with
+ * HIP events on the ctx stream: *ms = their summed duration since the last reset,
+ * *count (may be NULL) = how many exchanges that was. */
+int d3d_halo_time(d3d_ctx *ctx, double *ms, long *count, int reset);
 /* The same exchange in steps, for other transports: pack the send rectangles into
  * the plan's device send buffer / scatter the device receive buffer; device
  * pointers and sizes of one entry's buffers; host staging of one entry;

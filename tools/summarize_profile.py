@@ -102,7 +102,10 @@ with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
         p = os.path.join(src, name)
         if os.path.exists(p):
             fh.write("\n`%s`:\n\n```\n%s```\n" % (name, open(p).read()))
-json.dump({"tag": tag, "workload": "c3_300x300x128", "hbm_bytes_per_launch": traffic,
+sys.path.insert(0, root)
+from deconv3d_amd import _lib  # noqa: E402  (the library these counters were taken on)
+json.dump({"tag": tag, "workload": "c3_300x300x128", "source_hash": _lib.source_hash(),
+           "hbm_bytes_per_launch": traffic,
            "hbm_bytes_per_launch_variants": variants},
           open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
 print(open(os.path.join(dst, "%s_summary.md" % tag)).read()[:3000])
