@@ -137,6 +137,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
     if (c->Dp > 160 && c->mh_layers_cfg > 2) c->mh_layers_cfg = 2;
     if (c->mh_defer != 1 || c->mh_flow || c->Dp > 256) c->mh_layers_cfg = 1;
+    if (c->deep) c->mh_defer = 0;  // k_mh_deep writes the residual back at once
     c->mh_layers = c->mh_layers_cfg;
 }
 
@@ -508,10 +509,12 @@ int d3d_ctx_create(d3d_ctx **out, int device, int D, int H, int W, int fh, int f
     c->N = next_pow2_ref(D);
     c->HW = (long)H * W;
     c->cube_elems = (size_t)c->HW * c->Dp;
-    if (c->N > 1024 || c->Dp > 1024) {
+    if (c->N > d3d::MH_DEEP_MAX || c->Dp > d3d::MH_DEEP_MAX) {
         delete c;
-        return fail(D3D_ERR_UNSUPPORTED, "spectral depth %d exceeds the kernels' limit of 1024", D);
+        return fail(D3D_ERR_UNSUPPORTED, "spectral depth %d exceeds the kernels' limit of %d", D,
+                    d3d::MH_DEEP_MAX);
     }
+    c->deep = c->N > 1024 || c->Dp > 1024;
     c->sp_nt = pick_nt(c->HL);
     options_from_env(c);
     pick_mh_geometry(c);
@@ -1625,6 +1628,7 @@ int d3d_apply_updates(d3d_ctx *c, int n, const double *records) {
     NEED(c && (n == 0 || records), D3D_ERR_INVALID, "NULL argument");
     NEED(n >= 0 && n <= c->HW, D3D_ERR_INVALID, "bad record count %d", n);
     NEED(c->have_taps && c->have_data, D3D_ERR_STATE, "taps/data not set");
+    NEED(!c->deep, D3D_ERR_UNSUPPORTED, "update records are not replayed on cubes deeper than 1024 channels");
     if (n == 0) return D3D_OK;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->err_valid) {

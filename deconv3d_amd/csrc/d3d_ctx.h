@@ -49,6 +49,7 @@ struct d3d_ctx {
     int device = 0;
     int D = 0, H = 0, W = 0, fh = 0, fw = 0;
     int Dp = 0, HL = 0, N = 0;
+    bool deep = false;  // more than 1024 channels: the z-blocked kernel forms (k_*_deep)
     long HW = 0;
     size_t cube_elems = 0;  // HW * Dp
     hipStream_t own_stream = nullptr, stream = nullptr;

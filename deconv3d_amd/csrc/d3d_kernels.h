@@ -3544,6 +3544,226 @@ __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
     if (touched) *reinterpret_cast<double2 *>(P.err + vox * P.Dp + 2 * zl) = e;
 }
 
+// ------------------------------------------------------------------------- //
+// Deep cubes (more than 1024 channels: a full MUSE cube has ~3700)             //
+// ------------------------------------------------------------------------- //
+// The kernels above map a spectrum onto the threads of ONE workgroup, a z-pair per
+// thread: 1024 channels at most.  The reference takes any depth (lib/convolution.py:
+// 137-141 pads to the next power of two; lib/run.py:146-149).  Deeper cubes run the
+// forms below: the same arithmetic with a thread looping over its channels
+// (z-blocked), plain and unoptimised -- correct first (tests/test_gpu_edges.py up to
+// 3700 channels); up to MH_DEEP_MAX channels (the zero-extended unit lines of length
+// N = 2^k >= D must fit the LDS twice).
+constexpr int MH_DEEP_ZB = 4;               // z-pairs per thread of k_mh_deep (1024 threads)
+constexpr int MH_DEEP_MAX = 2 * 1024 * MH_DEEP_ZB;
+
+// k_lines for any depth: one workgroup per spaxel.
+static __global__ __launch_bounds__(1024) void k_lines_deep(SpectralArgs A,
+                                                            const double *__restrict__ params,
+                                                            const uint8_t *__restrict__ mask,
+                                                            double *__restrict__ out, int convolved) {
+    extern __shared__ double smem[];
+    const long sp = blockIdx.x;
+    const bool live = mask[sp] != 0;
+    const double a = params[sp * 3 + 0], c = params[sp * 3 + 1], w = params[sp * 3 + 2];
+    const bool use_lsf = convolved && A.ntaps > 0;
+    if (!use_lsf) {
+        for (int z = threadIdx.x; z < A.Dp; z += 1024)
+            out[sp * A.Dp + z] = (live && z < A.D) ? a * unit_gaussian((double)z, c, w) : 0.0;
+        return;
+    }
+    for (int j = threadIdx.x; j < A.N; j += 1024)
+        smem[j] = (live && j < A.D) ? a * unit_gaussian((double)j, c, w) : 0.0;
+    __syncthreads();
+    for (int z = threadIdx.x; z < A.Dp; z += 1024)
+        out[sp * A.Dp + z] = (live && z < A.D) ? lsf_apply(smem, z, A) : 0.0;
+}
+
+// k_spectral for any depth.
+static __global__ __launch_bounds__(1024) void k_spectral_deep(SpectralArgs A,
+                                                               const double *__restrict__ in,
+                                                               double *__restrict__ out) {
+    extern __shared__ double smem[];
+    const long sp = blockIdx.x;
+    for (int j = threadIdx.x; j < A.N; j += 1024) smem[j] = (j < A.D) ? in[sp * A.Dp + j] : 0.0;
+    __syncthreads();
+    for (int z = threadIdx.x; z < A.Dp; z += 1024)
+        out[sp * A.Dp + z] = (z < A.D) ? lsf_apply(smem, z, A) : 0.0;
+}
+
+// k_spatial_generic for any depth: grid (spaxels, z-chunks of 256 z-pairs).
+static __global__ __launch_bounds__(256) void k_spatial_deep(SpatialArgs A,
+                                                             const double *__restrict__ in,
+                                                             double *__restrict__ out) {
+    const long sp = blockIdx.x;
+    const int zl = blockIdx.y * 256 + threadIdx.x;
+    if (zl >= A.HL) return;
+    const int y = (int)(sp / A.W), x = (int)(sp - (long)y * A.W);
+    const int fhh = (A.fh - 1) / 2, fhw = (A.fw - 1) / 2;
+    double2 acc = make_double2(0.0, 0.0);
+    for (int j = 0; j < A.fh; ++j) {
+        const int yy = y - j + fhh;
+        if (yy < 0 || yy >= A.H) continue;
+        for (int i = 0; i < A.fw; ++i) {
+            const int xx = x - i + fhw;
+            if (xx < 0 || xx >= A.W) continue;
+            const double tap = A.fsf[j * A.fw + i];
+            const double2 v =
+                *reinterpret_cast<const double2 *>(in + ((long)yy * A.W + xx) * A.Dp + 2 * zl);
+            acc.x = fma(tap, v.x, acc.x);
+            acc.y = fma(tap, v.y, acc.y);
+        }
+    }
+    const long o = sp * A.Dp + 2 * zl;
+    if (A.data) {
+        const double2 d = *reinterpret_cast<const double2 *>(A.data + o);
+        acc.x = d.x - acc.x;
+        acc.y = d.y - acc.y;
+    }
+    *reinterpret_cast<double2 *>(out + o) = acc;
+}
+
+__host__ __device__ inline size_t mh_deep_lds_doubles(int N, int npos) {
+    return (size_t)npos + 2 * (size_t)N + 8 * 16 + 8;
+}
+
+// The terms one channel adds to the seven sums of the decision (mh_channel_sums).
+__device__ __forceinline__ void mh_channel_terms(const MHProposal &q, double EO, double EN, double Az,
+                                                 double Bz, double Cz, double (&s)[7]) {
+    const double a_new = q.pn[0];
+    const double Lo = q.a_old * EO;
+    const double d = Lo - a_new * EN;
+    const double ulB = Az + Lo * Bz;
+    s[0] += d * Az;
+    s[1] += d * d * Bz;
+    s[2] += Cz;
+    s[3] += EO * EO * Bz;
+    s[4] += EO * ulB;
+    s[5] += EN * EN * Bz;
+    s[6] += EN * ulB;
+}
+
+// One MH-within-Gibbs update per workgroup (lib/run.py:367-519), immediate write-back, any
+// depth up to MH_DEEP_MAX: k_mh with every thread looping over its z-pairs tid, tid + 1024,
+// ...  The window sums stay in registers (one position group), the zero-extended unit lines
+// go to LDS, the decision is mh_decide_wave's.  Probe and external-lines modes as k_mh.
+static __global__ __launch_bounds__(1024) void k_mh_deep(MHArgs P, uint32_t sweep) {
+    extern __shared__ double smem[];
+    constexpr int NT = 1024, ZB = MH_DEEP_ZB;
+    const int tid = threadIdx.x;
+    const int HL = P.HL, Dp = P.Dp, N = P.N, npos = P.npos;
+    const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
+    MHShared S = {};
+    S.fsf = smem;
+    S.gO = smem + npos;
+    S.gN = S.gO + N;
+    S.sum = S.gN + N;
+    int sp;
+    if (P.probe) {
+        sp = P.probe_sp;
+    } else if (P.ext_lines) {
+        sp = P.ext_idx[blockIdx.x];
+    } else {
+        const int4 ent = P.spx[blockIdx.x];
+        sp = ent.x * P.W + ent.y;
+    }
+    const int y = sp / P.W, x = sp - y * P.W;
+    for (int p = tid; p < npos; p += NT) S.fsf[p] = P.fsf[p];
+    // the decision's window-independent part first: proposal and zero-extended unit lines
+    const MHProposal q = mh_propose(P, sp, sweep);
+    for (int j = tid; j < N; j += NT) {
+        if (P.ext_lines) {
+            const double *L = P.ext_lines + (long)blockIdx.x * 2 * P.D;
+            S.gO[j] = (j < P.D) ? L[j] : 0.0;
+            S.gN[j] = (j < P.D) ? L[P.D + j] : 0.0;
+        } else {
+            S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
+            S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 1: window sums per channel, in registers ---------------------------------
+    double2 wA[ZB], wB[ZB], wC[ZB];
+#pragma unroll
+    for (int j = 0; j < ZB; ++j) wA[j] = wB[j] = wC[j] = make_double2(0.0, 0.0);
+    for (int pw = 0; pw < npos; ++pw) {
+        const int p = P.rev ? npos - 1 - pw : pw;
+        const int dy = p / P.fw, dx = p - dy * P.fw;
+        const int yy = y + dy - fhh, xx = x + dx - fhw;
+        if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+        const double f = S.fsf[p];
+        const long base = ((long)yy * P.W + xx) * Dp;
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+            const int zl = tid + j * NT;
+            if (zl < HL) {
+                const double2 e = *reinterpret_cast<const double2 *>(P.err + base + 2 * zl);
+                const double2 v = *reinterpret_cast<const double2 *>(P.ivar + base + 2 * zl);
+                double2 sA = wA[j], sB = wB[j], sC = wC[j];
+                D3D_ACCUM(e, v, f);
+                wA[j] = sA;
+                wB[j] = sB;
+                wC[j] = sC;
+            }
+        }
+    }
+    // ---- the seven sums over this thread's channels, then over the workgroup ----------------
+    double s7[7] = {0, 0, 0, 0, 0, 0, 0};
+    double2 EOr[ZB], ENr[ZB];
+#pragma unroll
+    for (int j = 0; j < ZB; ++j) {
+        EOr[j] = ENr[j] = make_double2(0.0, 0.0);
+        const int zl = tid + j * NT;
+        if (zl < HL) {
+            mh_lsf(P, S.gO, S.gN, 2 * zl, &EOr[j].x, &ENr[j].x);
+            mh_lsf(P, S.gO, S.gN, 2 * zl + 1, &EOr[j].y, &ENr[j].y);
+            if (2 * zl < P.D) mh_channel_terms(q, EOr[j].x, ENr[j].x, wA[j].x, wB[j].x, wC[j].x, s7);
+            if (2 * zl + 1 < P.D) mh_channel_terms(q, EOr[j].y, ENr[j].y, wA[j].y, wB[j].y, wC[j].y, s7);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s7[k] = wave_sum_dpp63(s7[k]);
+    if ((tid & 63) == 63) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) S.sum[(tid >> 6) * 8 + k] = s7[k];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const U2 u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
+        mh_decide_wave(P, S, q, sp, sweep, NT / 64, u_gibbs);
+    }
+    __syncthreads();
+    if (P.probe) return;
+
+    // ---- pass 2: write the window back --------------------------------------------------
+    double2 Gz[ZB];
+#pragma unroll
+    for (int j = 0; j < ZB; ++j) {
+        const int zl = tid + j * NT;
+        Gz[j].x = mh_update_coeff(P, S, q, 2 * zl, EOr[j].x, ENr[j].x, NT / 64);
+        Gz[j].y = mh_update_coeff(P, S, q, 2 * zl + 1, EOr[j].y, ENr[j].y, NT / 64);
+    }
+    for (int pw = 0; pw < npos; ++pw) {
+        const int p = P.rev ? npos - 1 - pw : pw;
+        const int dy = p / P.fw, dx = p - dy * P.fw;
+        const int yy = y + dy - fhh, xx = x + dx - fhw;
+        if (yy < 0 || yy >= P.H || xx < 0 || xx >= P.W) continue;
+        const double f = S.fsf[p];
+        const long base = ((long)yy * P.W + xx) * Dp;
+#pragma unroll
+        for (int j = 0; j < ZB; ++j) {
+            const int zl = tid + j * NT;
+            if (zl < HL) {
+                double2 e = *reinterpret_cast<const double2 *>(P.err + base + 2 * zl);
+                e.x = fma(f, Gz[j].x, e.x);
+                e.y = fma(f, Gz[j].y, e.y);
+                *reinterpret_cast<double2 *>(P.err + base + 2 * zl) = e;
+            }
+        }
+    }
+}
+
 // Halo exchange of the tiled chain: the cells (all E values per spaxel: E = Dp for
 // a cube, 3 for the parameter map) of the rectangle [y0,y1) x [x0,x1) of a (H,W,E)
 // array to / from a packed buffer.  A row of the rectangle is one contiguous run.

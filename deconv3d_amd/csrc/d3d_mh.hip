@@ -125,6 +125,14 @@ int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
 }
 
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    if (c->deep) {  // more than 1024 channels: threads loop over their z-pairs
+        const size_t lds = d3d::mh_deep_lds_doubles(c->N, P.npos) * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(d3d::k_mh_deep),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(d3d::k_mh_deep, dim3(grid), dim3(1024), lds, c->stream, P, sweep);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     switch (c->mh_nt) {
         case 128: return launch_mh_nt<128>(c, P, grid, sweep);
         case 256: return launch_mh_nt<256>(c, P, grid, sweep);

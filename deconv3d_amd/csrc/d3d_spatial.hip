@@ -41,6 +41,16 @@ int launch_lines_nt(d3d_ctx *c, double *out, int convolved, const double *params
 // params: (H,W,3) map on the device (NULL: the chain state c->params)
 int launch_lines(d3d_ctx *c, double *out, int convolved, const double *params) {
     if (!params) params = c->params;
+    if (c->deep) {
+        d3d::SpectralArgs A = spectral_args(c);
+        const size_t lds = (size_t)c->N * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(d3d::k_lines_deep),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(d3d::k_lines_deep, dim3((unsigned)c->HW), dim3(1024), lds, c->stream, A,
+                           params, (const uint8_t *)c->mask, out, convolved);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     switch (pick_nt(c->HL)) {
         case 256: return launch_lines_nt<256>(c, out, convolved, params);
         case 512: return launch_lines_nt<512>(c, out, convolved, params);
@@ -61,6 +71,16 @@ int launch_spectral_nt(d3d_ctx *c, const double *in, double *out) {
 }
 
 int launch_spectral(d3d_ctx *c, const double *in, double *out) {
+    if (c->deep) {
+        d3d::SpectralArgs A = spectral_args(c);
+        const size_t lds = (size_t)c->N * sizeof(double);
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(d3d::k_spectral_deep),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(d3d::k_spectral_deep, dim3((unsigned)c->HW), dim3(1024), lds, c->stream, A,
+                           in, out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (c->lsf_fusable && c->spectral_dense) {
         // dense +-LSF_RL taps, spectrum within one wavefront: streaming form
         const int NT = 256, G = NT / c->HL;
@@ -407,6 +427,7 @@ int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *da
 
 // True when the spatial pass can apply the LSF itself (fused epilogue).
 bool can_fuse_lsf(const d3d_ctx *c) {
+    if (c->deep) return false;
     // (an outer-product FSF honours D3D_SEP_FUSE=0: LSF in its own pass, for A/B tests)
     if (conv_rows_usable(c, true) && !(c->fsf_sep && c->march_mode > 0 && !c->sep_fuse)) return true;
     if (!c->lsf_fusable || c->march_mode <= 0 || c->fh != c->fw) return false;
@@ -429,6 +450,22 @@ bool can_fuse_lsf(const d3d_ctx *c) {
 int launch_spatial(d3d_ctx *c, const double *in, double *out, const double *data,
                    bool fuse_lsf) {
     if (conv_rows_usable(c, fuse_lsf)) return launch_conv_rows(c, in, out, data, fuse_lsf);
+    if (c->deep) {
+        if (fuse_lsf) return fail(D3D_ERR_STATE, "internal: fused LSF requested on a deep cube");
+        d3d::SpatialArgs A = {};
+        A.Dp = c->Dp;
+        A.HL = c->HL;
+        A.H = c->H;
+        A.W = c->W;
+        A.fh = c->fh;
+        A.fw = c->fw;
+        A.fsf = c->fsf;
+        A.data = data;
+        hipLaunchKernelGGL(d3d::k_spatial_deep, dim3((unsigned)c->HW, (unsigned)((c->HL + 255) / 256)),
+                           dim3(256), 0, c->stream, A, in, out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     int nt = pick_nt(c->HL);
     if (c->sp_nt_opt >= nt) nt = c->sp_nt_opt;
     switch (nt) {

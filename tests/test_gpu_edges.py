@@ -28,11 +28,12 @@ def small_problem(D, H, W, fsf, lsf, seed=0):
     return data, var, mask, truth, init, min_b, max_b
 
 
-@pytest.mark.parametrize("D", [100, 128, 200, 256, 300, 512, 1000, 1024])
+@pytest.mark.parametrize("D", [100, 128, 200, 256, 300, 512, 1000, 1024, 1025, 2048, 3700])
 def test_deep_cubes_chain_matches_oracle(D):
     """Depths that select every MH kernel: wave-specialised (D <= 256), plain
-    deferred (D > 256), 256/512/1024-thread blocks, and
-    non-power-of-two depths with the partial-wrap LSF."""
+    deferred (D > 256), 256/512/1024-thread blocks, the z-blocked forms beyond 1024
+    channels (a full MUSE cube has ~3700; lib/convolution.py:137-141 takes any depth),
+    and non-power-of-two depths with the partial-wrap LSF."""
     H, W = 5, 6
     fsf = O.gaussian_fsf_image(1.6)
     lsf = O.gaussian_lsf_vector(D, 1.1)
@@ -56,8 +57,33 @@ def test_deep_cubes_chain_matches_oracle(D):
 
 
 def test_depth_limit_is_reported():
-    with pytest.raises(NotImplementedError, match="1024"):
-        _lib.Engine((1025, 4, 4), (3, 3))
+    with pytest.raises(NotImplementedError, match="8192"):
+        _lib.Engine((8193, 4, 4), (3, 3))
+
+
+def test_deep_cube_probe_convolution_and_run():
+    """The other entry points on a 2500-channel cube: window probe, LSF (x) FSF of an
+    arbitrary cube in both layouts, chi2 map -- against the oracle."""
+    D, H, W = 2500, 4, 5
+    fsf = O.gaussian_fsf_image(1.2)
+    lsf = O.gaussian_lsf_vector(D, 1.4)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=7)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(init)
+        err = eng.residual()
+        ref = O.compute_error_in_one_step(data, init, mask, fsf, lsf)
+        assert np.max(np.abs(err - ref)) <= 1e-12 * np.max(np.abs(ref))
+        p_new = init[2, 3] + np.array([0., 0.7, 0.1])
+        got = eng.window_stats(2, 3, p_new)
+        want = O.window_stats(err, var, init[2, 3], p_new, 2, 3, fsf, lsf)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12 * want[0])
+        cube = np.random.default_rng(1).normal(size=(D, H, W))
+        conv = O.convolve_cube(cube, fsf, lsf)
+        assert np.max(np.abs(eng.convolve(cube) - conv)) <= 1e-12 * np.max(np.abs(conv))
+        cmap, total = eng.chi2_map()
+        np.testing.assert_allclose(cmap, 0.5 * np.sum(err ** 2 / var, axis=0), rtol=1e-10)
 
 
 def test_nan_voxels_and_zero_variance():
