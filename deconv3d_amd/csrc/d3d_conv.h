@@ -49,12 +49,27 @@ struct ConvRowsArgs {
 //   wl    dense LSF weights [2*LSF_RL+1] (LSF); LSYM: mirror-symmetric, first RL+1 read
 //   data  residual epilogue out = data - conv (RESID)
 
-constexpr int CONV_DP = 128;  // doubles per spectrum: one wavefront of z-pairs
+constexpr int CONV_DP = 128;  // doubles per wavefront: 64 z-pairs
 constexpr int CONV_NBUF = 4;  // LDS ring of input rows: two PAIRS (one read, one in flight)
 
-template <int FS, int NW>
+// DPS = doubles per spectrum (the cube's padded depth): 128 -- one wavefront, one output
+// column -- or 64 / 32: a wavefront owns SPW = 128 / DPS ADJACENT output columns, lane group
+// g = lane / (DPS/2) the column x + g.  Adjacent spectra are adjacent in memory and in the
+// LDS rows, so a wavefront's 1 KiB accesses stay contiguous and the stencil's column
+// offsets become multiples of DPS doubles instead of 128.
+template <int FS, int NW, int DPS>
+struct ConvGeo {
+    static constexpr int SPW = CONV_DP / DPS;                        // spectra per wavefront
+    static constexpr int NWC = NW * SPW;                             // output columns per workgroup
+    static constexpr int RLEN = (NWC + FS - 1) * DPS;                // doubles of an input row segment
+    static constexpr int NCH = (RLEN + CONV_DP - 1) / CONV_DP;       // 1 KiB chunks the loader moves
+    static constexpr int RBUF = NCH * CONV_DP;                       // doubles per LDS row buffer
+    static constexpr int SPEC = SPW * (DPS + 2 * LSF_RL);            // LSF scratch per wavefront
+};
+
+template <int FS, int NW, int DPS = CONV_DP>
 __host__ __device__ constexpr size_t conv_rows_lds_bytes() {
-    return ((size_t)CONV_NBUF * (NW + FS - 1) * CONV_DP + (size_t)NW * (CONV_DP + 2 * LSF_RL) +
+    return ((size_t)CONV_NBUF * ConvGeo<FS, NW, DPS>::RBUF + (size_t)NW * ConvGeo<FS, NW, DPS>::SPEC +
             CONV_DP) * sizeof(double);
 }
 
@@ -75,17 +90,19 @@ __device__ __forceinline__ void conv_glds16(const double *gsrc, double *lds_dst)
 // when tap rows FHH-a / FHH+a reach an output row of the strip at all: that skips the
 // dot products of the first and last FHH steps (10 % of a strip's FMAs) for one scalar
 // bit test each.
-template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH>
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH, int DPS>
 __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long rowstride, int x,
-                                               int wave, int lane, const double *rows,
+                                               bool xok, int wave, int lane, const double *rows,
                                                double *myspec,
                                                const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
                                                const double (&w)[2 * LSF_RL + 1],
                                                const double *__restrict__ data,
                                                double *__restrict__ out, double2 (&ring)[FS],
                                                double2 &dnext) {
-    constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, NC = NW + FS - 1, DP = CONV_DP;
+    constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, DP = DPS;
     constexpr int NBUF = CONV_NBUF, RL = LSF_RL;
+    constexpr int RBUF = ConvGeo<FS, NW, DPS>::RBUF, HLS = DPS / 2;
+    const int zl = lane % HLS;        // z-pair within the spectrum (lane group g = lane / HLS)
     const int oy = y0 - 2 * FHH + i;  // the output row this step finishes
     const bool store = oy >= y0;      // (oy < yend always: i < nsteps)
     // tap rows at distance a from the centre reach output rows r-a and r+a, r = y0-FHH+i:
@@ -98,12 +115,12 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
     const double2 dcur = dnext;
     if constexpr (RESID) {
         // one step ahead: the data row of the output finished by step i+1
-        if (oy + 1 >= y0 && oy + 1 < yend)
+        if (xok && oy + 1 >= y0 && oy + 1 < yend)
             dnext = *reinterpret_cast<const double2 *>(data + (long)(oy + 1) * rowstride +
-                                                       (long)x * DP + 2 * lane);
+                                                       (long)x * DP + 2 * zl);
     }
     {
-        const double *rb = rows + ((size_t)(i % NBUF) * NC + wave) * DP + 2 * lane;
+        const double *rb = rows + (size_t)(i % NBUF) * RBUF + (size_t)wave * CONV_DP + 2 * lane;
         // P[e]: the two inputs at distance e from the output's column, folded
         double2 P[NQ];
         P[0] = *reinterpret_cast<const double2 *>(rb + (size_t)FHH * DP);
@@ -175,11 +192,12 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
         if constexpr (LSF) {
             // LSF on the finished row: spectrum -> wave-private LDS buffer with a circular
             // halo of RL channels -> aligned 16-byte window reads
-            *reinterpret_cast<double2 *>(myspec + RL + 2 * lane) = v;
-            if (2 * lane < RL) *reinterpret_cast<double2 *>(myspec + DP + RL + 2 * lane) = v;
-            if (2 * lane >= DP - RL) *reinterpret_cast<double2 *>(myspec + RL + 2 * lane - DP) = v;
+            double *ms = myspec + (size_t)(lane / HLS) * (DP + 2 * RL);   // this lane group's spectrum
+            *reinterpret_cast<double2 *>(ms + RL + 2 * zl) = v;
+            if (2 * zl < RL) *reinterpret_cast<double2 *>(ms + DP + RL + 2 * zl) = v;
+            if (2 * zl >= DP - RL) *reinterpret_cast<double2 *>(ms + RL + 2 * zl - DP) = v;
             __builtin_amdgcn_wave_barrier();  // LDS is in order per wavefront
-            const double *bt = myspec + 2 * lane;
+            const double *bt = ms + 2 * zl;
             double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
             for (int j = 0; j < RL + 1; ++j) {
@@ -197,21 +215,16 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
             v.x = dcur.x - v.x;
             v.y = dcur.y - v.y;
         }
-        double2 *dst = reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * lane);
-#if defined(D3D_CONV_NT)
-        __builtin_nontemporal_store(v.x, &dst->x);
-        __builtin_nontemporal_store(v.y, &dst->y);
-#else
-        *dst = v;
-#endif
+        double2 *dst = reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * zl);
+        if (xok) *dst = v;
     }
 }
 
 // FS consecutive steps starting at step `base` (base mod FS == 0), a workgroup barrier
 // before every even step: input rows travel in PAIRS (see the loader).
-template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH = 0>
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int DPS, int PH = 0>
 __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, int yend,
-                                                long rowstride, int x, int wave, int lane,
+                                                long rowstride, int x, bool xok, int wave, int lane,
                                                 const double *rows, double *myspec,
                                                 const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
                                                 const double (&w)[2 * LSF_RL + 1],
@@ -223,32 +236,33 @@ __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, in
         if (i < nsteps) {
             // (every LDS read of the previous pair has been consumed: data dependences)
             if ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            conv_rows_step<FS, NW, LSF, RESID, SEP, PH>(i, y0, yend, rowstride, x, wave, lane, rows,
-                                                        myspec, q, w, data, out, ring, dnext);
+            conv_rows_step<FS, NW, LSF, RESID, SEP, PH, DPS>(i, y0, yend, rowstride, x, xok, wave, lane,
+                                                             rows, myspec, q, w, data, out, ring, dnext);
             // keep the steps apart: interleaving two of them costs more registers than the
             // 128 that four wavefronts per SIMD allow
             __builtin_amdgcn_sched_barrier(0);
         }
-        conv_rows_steps<FS, NW, LSF, RESID, SEP, PH + 1>(base, nsteps, y0, yend, rowstride, x, wave,
-                                                         lane, rows, myspec, q, w, data, out, ring,
-                                                         dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, SEP, DPS, PH + 1>(base, nsteps, y0, yend, rowstride, x, xok,
+                                                              wave, lane, rows, myspec, q, w, data, out,
+                                                              ring, dnext);
     }
 }
 
 // TSYM = 2 selects the outer-product form (SEP): quad holds v[e] (row 0) and u[a] (row 1).
-template <int FS, int NW, bool LSF, bool LSYM, bool RESID, int TSYM>
+template <int FS, int NW, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = CONV_DP>
 __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                                                               const double *__restrict__ in,
                                                               double *__restrict__ out,
                                                               const double *__restrict__ quad,
                                                               const double *__restrict__ wl,
                                                               const double *__restrict__ data) {
-    constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, NC = NW + FS - 1, DP = CONV_DP;
+    constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, DP = DPS;
     constexpr int NBUF = CONV_NBUF, RL = LSF_RL;
+    using Geo = ConvGeo<FS, NW, DPS>;
+    constexpr int NCH = Geo::NCH, RBUF = Geo::RBUF, SPW = Geo::SPW, NWC = Geo::NWC, HLS = DPS / 2;
     extern __shared__ double smem[];
-    double *rows = smem;                                // [NBUF][NC][DP]
-    double *spec = rows + (size_t)NBUF * NC * DP;       // [NW][DP + 2 RL]
-    double *dummy = spec + (size_t)NW * (DP + 2 * RL);  // [DP]: target of out-of-range loads
+    double *rows = smem;                                // [NBUF][RBUF]: (NWC + FS - 1) spectra per row
+    double *spec = rows + (size_t)NBUF * RBUF;          // [NW][SPW][DP + 2 RL]
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     // XCD-aware block order: consecutive LOGICAL blocks (x-neighbours of one row
@@ -259,7 +273,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
         blk = (xcd < rm ? xcd * (qq + 1) : rm * (qq + 1) + (xcd - rm) * qq) + blk / 8;
     }
     const int gy = blk / A.ngx, gx = blk - gy * A.ngx;
-    const int x0 = gx * NW, y0 = gy * A.HY;
+    const int x0 = gx * NWC, y0 = gy * A.HY;
     const int yend = min(y0 + A.HY, A.H);
     const int nsteps = (yend - y0) + 2 * FHH;
     const int npairs = (nsteps + 1) / 2;
@@ -271,32 +285,36 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
         // waves read pair j, pair j+1 is in flight (<= 2 NC = 50 loads outstanding,
         // under the 63 a wavefront may have); its buffers held pair j-1, whose readers
         // passed the barrier that precedes the issue.
-        for (int c = 0; c < NC; ++c) {
-            const int xx = x0 - FHH + c;
+        // chunk c of a row segment: doubles [128 c, 128 c + 128) from column x0 - FHH on; lane l
+        // holds doubles 128 c + 2 l, + 1, i.e. column xs + (128 c + 2 l) / DPS.  A lane whose
+        // column lies outside the cube never loads: its LDS slot keeps the zero written here.
+        const int xs = x0 - FHH;
+        auto lane_col = [&](int c) { return xs + (c * CONV_DP + 2 * lane) / DP; };
+        for (int c = 0; c < NCH; ++c) {
+            const int xx = lane_col(c);
             if (xx < 0 || xx >= A.W)
                 for (int b = 0; b < NBUF; ++b)
-                    *reinterpret_cast<double2 *>(rows + ((size_t)b * NC + c) * DP + 2 * lane) =
+                    *reinterpret_cast<double2 *>(rows + (size_t)b * RBUF + (size_t)c * CONV_DP + 2 * lane) =
                         make_double2(0.0, 0.0);
         }
         auto issue = [&](int i) {
             const int r = y0 - FHH + i;
             if (i >= nsteps) return;
-            double *dst = rows + (size_t)(i % NBUF) * NC * DP;
+            double *dst = rows + (size_t)(i % NBUF) * RBUF;
             if (r < 0 || r >= A.H) {  // a row outside the cube is a row of zeros
-                for (int c = 0; c < NC; ++c)
-                    *reinterpret_cast<double2 *>(dst + (size_t)c * DP + 2 * lane) =
+                for (int c = 0; c < NCH; ++c)
+                    *reinterpret_cast<double2 *>(dst + (size_t)c * CONV_DP + 2 * lane) =
                         make_double2(0.0, 0.0);
                 return;
             }
-            const double *src = in + (long)r * rowstride + 2 * lane;
+            const double *src = in + (long)r * rowstride + (long)xs * DP + 2 * lane;
 #if defined(D3D_CONV_DIAG) && D3D_CONV_DIAG == 1
             return;  // diagnostic: no loads at all (compute floor)
 #endif
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int xx = x0 - FHH + c;
-                const bool ok = xx >= 0 && xx < A.W;
-                conv_glds16(src + (long)(ok ? xx : 0) * DP, ok ? dst + (size_t)c * DP : dummy);
+            for (int c = 0; c < NCH; ++c) {
+                const int xx = lane_col(c);
+                if (xx >= 0 && xx < A.W) conv_glds16(src + (long)c * CONV_DP, dst + (size_t)c * CONV_DP);
             }
         };
         __builtin_amdgcn_s_setprio(3);  // the loads are on everybody's critical path (-1 us)
@@ -312,9 +330,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
         return;
     }
 
-    // ---- compute wavefront: output column x0 + wave --------------------------------
-    const int x = x0 + wave;
-    if (x >= A.W) {  // a column past the cube's edge: only keep the barriers company
+    // ---- compute wavefront: output columns x0 + wave SPW + (lane group) -------------------
+    const int x = x0 + wave * SPW + lane / HLS;
+    const bool xok = x < A.W;
+    if (x0 + wave * SPW >= A.W) {  // columns past the cube's edge: only keep the barriers company
         asm volatile("s_barrier" ::: "memory");
         for (int j = 0; j < npairs; ++j) asm volatile("s_barrier" ::: "memory");
         return;
@@ -346,13 +365,13 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
     double2 ring[FS];
 #pragma unroll
     for (int k = 0; k < FS; ++k) ring[k] = make_double2(0.0, 0.0);
-    double *myspec = spec + (size_t)wave * (DP + 2 * RL);
+    double *myspec = spec + (size_t)wave * Geo::SPEC;
     double2 dnext = make_double2(0.0, 0.0);  // RESID: data of the row finished next
     asm volatile("s_barrier" ::: "memory");  // prologue
     // blocks of FS steps (the ring rotates through static registers)
     for (int base = 0; base < nsteps; base += FS)
-        conv_rows_steps<FS, NW, LSF, RESID, TSYM == 2>(base, nsteps, y0, yend, rowstride, x, wave, lane,
-                                                       rows, myspec, q, w, data, out, ring, dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, TSYM == 2, DPS>(base, nsteps, y0, yend, rowstride, x, xok, wave,
+                                                            lane, rows, myspec, q, w, data, out, ring, dnext);
 }
 
 }  // namespace d3d

@@ -356,22 +356,26 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
 // Usable for a 128-channel spectrum (one wavefront per column) and a square FSF with
 // both mirror symmetries; with_lsf additionally needs the dense power-of-two LSF form.
 bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
-    if (!c->conv_rows || c->Dp != d3d::CONV_DP) return false;
+    if (!c->conv_rows) return false;
     if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
     if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D)) return false;
+    if (c->Dp == 64 || c->Dp == 32)  // several spectra per wavefront: the BASELINE footprints
+        return c->fw == 9 || c->fw == 11;
+    if (c->Dp != d3d::CONV_DP) return false;
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: return true;
         default: return false;
     }
 }
 
-template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM>
+template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = d3d::CONV_DP>
 int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
     constexpr int NW = 15;
+    constexpr int NWC = d3d::ConvGeo<FS, NW, DPS>::NWC;  // output columns per workgroup
     d3d::ConvRowsArgs A;
     A.H = c->H;
     A.W = c->W;
-    A.ngx = (c->W + NW - 1) / NW;
+    A.ngx = (c->W + NWC - 1) / NWC;
     // one workgroup per CU (1024 threads, ~93 KB of LDS): as many row strips as fill the
     // chip in ONE round
     const int cus = c->flow_grid > 0 ? c->flow_grid / 4 : 256;
@@ -381,8 +385,8 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
     if (c->conv_hy_opt >= 1) A.HY = c->conv_hy_opt;
     A.ngy = (c->H + A.HY - 1) / A.HY;
     A.xcd_remap = 1;
-    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM>;
-    constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW>();
+    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM, DPS>;
+    constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW, DPS>();
     // > 64 KB of dynamic LDS has to be allowed per function AND per device: set on every
     // launch (a host-side call of a few microseconds; this kernel is not in the MH loop)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -394,27 +398,33 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
     return 0;
 }
 
-template <int FS, int TSYM>
+template <int FS, int TSYM, int DPS = d3d::CONV_DP>
 int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
     const bool sym = c->lsf_dense_sym;
     if (lsf) {
-        if (data) return sym ? launch_conv_rows_t<FS, true, true, true, TSYM>(c, in, out, data)
-                             : launch_conv_rows_t<FS, true, false, true, TSYM>(c, in, out, data);
-        return sym ? launch_conv_rows_t<FS, true, true, false, TSYM>(c, in, out, data)
-                   : launch_conv_rows_t<FS, true, false, false, TSYM>(c, in, out, data);
+        if (data) return sym ? launch_conv_rows_t<FS, true, true, true, TSYM, DPS>(c, in, out, data)
+                             : launch_conv_rows_t<FS, true, false, true, TSYM, DPS>(c, in, out, data);
+        return sym ? launch_conv_rows_t<FS, true, true, false, TSYM, DPS>(c, in, out, data)
+                   : launch_conv_rows_t<FS, true, false, false, TSYM, DPS>(c, in, out, data);
     }
-    if (data) return launch_conv_rows_t<FS, false, false, true, TSYM>(c, in, out, data);
-    return launch_conv_rows_t<FS, false, false, false, TSYM>(c, in, out, data);
+    if (data) return launch_conv_rows_t<FS, false, false, true, TSYM, DPS>(c, in, out, data);
+    return launch_conv_rows_t<FS, false, false, false, TSYM, DPS>(c, in, out, data);
 }
 
-template <int FS>
+template <int FS, int DPS = d3d::CONV_DP>
 int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2>(c, in, out, data, lsf);
-    if (c->fsf_symt) return launch_conv_rows_ts<FS, 1>(c, in, out, data, lsf);
-    return launch_conv_rows_ts<FS, 0>(c, in, out, data, lsf);
+    if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2, DPS>(c, in, out, data, lsf);
+    if (c->fsf_symt) return launch_conv_rows_ts<FS, 1, DPS>(c, in, out, data, lsf);
+    return launch_conv_rows_ts<FS, 0, DPS>(c, in, out, data, lsf);
 }
 
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+    if (c->Dp == 64)
+        return c->fw == 9 ? launch_conv_rows_fs<9, 64>(c, in, out, data, lsf)
+                          : launch_conv_rows_fs<11, 64>(c, in, out, data, lsf);
+    if (c->Dp == 32)
+        return c->fw == 9 ? launch_conv_rows_fs<9, 32>(c, in, out, data, lsf)
+                          : launch_conv_rows_fs<11, 32>(c, in, out, data, lsf);
     switch (c->fw) {
         case 3: return launch_conv_rows_fs<3>(c, in, out, data, lsf);
         case 5: return launch_conv_rows_fs<5>(c, in, out, data, lsf);

@@ -1,6 +1,6 @@
 """
-k_conv_rows (csrc/d3d_conv.h): the one-pass LSF (x) FSF convolution for 128-channel
-cubes and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
+k_conv_rows (csrc/d3d_conv.h): the one-pass LSF (x) FSF convolution for 128-, 64- and
+32-channel cubes and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
 register rings + LSF epilogue -- against the oracle's restatement of
 lib/convolution.py:89-120 and lib/run.py:1027-1029, and against the two-pass
 kernels it replaces (option conv_rows = 0).  Shapes chosen to hit every border case of
@@ -41,6 +41,16 @@ CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
     (128, 26, 31, 13, "asym", 9),
     (128, 12, 30, 3, "muse", None),
     (127, 14, 22, 11, "muse", None),      # padded depth: LSF not power-of-two -> FSF pass only
+    # 64 / 32 channels: two / four adjacent columns per wavefront (BASELINE configs 2 and 1)
+    (64, 23, 31, 11, "muse", None),
+    (64, 40, 30, 11, "asym", 7),          # exactly one workgroup's 30 columns
+    (64, 9, 61, 9, "muse", 4),            # 2 workgroups + one column
+    (64, 26, 1, 11, "muse", 6),           # a single column: half a wavefront idle
+    (64, 12, 29, 9, "none", None),
+    (32, 16, 16, 9, "muse", None),        # config 1's footprint
+    (32, 21, 63, 11, "asym", 5),          # 60 columns per workgroup + 3
+    (32, 7, 2, 9, "muse", None),
+    (63, 14, 22, 11, "muse", None),       # padded depth 64: FSF pass only
 ]
 
 
@@ -63,7 +73,8 @@ def test_one_pass_convolution_matches_the_oracle_and_the_two_pass_kernels(D, H, 
     assert np.max(np.abs(outs[0] - outs[1])) <= 1e-13 * scale
 
 
-@pytest.mark.parametrize("D,H,W,fs,hy", [(128, 21, 34, 11, 8), (128, 17, 16, 9, None)])
+@pytest.mark.parametrize("D,H,W,fs,hy", [(128, 21, 34, 11, 8), (128, 17, 16, 9, None),
+                                         (64, 21, 34, 11, 8), (32, 17, 16, 9, None)])
 def test_forward_model_and_residual_through_the_one_pass_kernel(D, H, W, fs, hy):
     """params -> lines -> FSF, plain and with the data - sim epilogue
     (lib/run.py:999-1031), with masked spaxels."""
@@ -86,12 +97,13 @@ def test_forward_model_and_residual_through_the_one_pass_kernel(D, H, W, fs, hy)
     assert np.max(np.abs(err - (data - want))) <= 1e-12 * np.max(np.abs(data - want))
 
 
-def test_one_pass_kernel_is_position_independent():
+@pytest.mark.parametrize("D", [128, 64, 32])
+def test_one_pass_kernel_is_position_independent(D):
     """The march always runs top-down: a cube cut out of a larger one (with the FSF
     half width of context) gives the very same bits on the common interior -- which is
     what lets a tile rebuild its residual and agree with the full cube."""
     rng = np.random.default_rng(11)
-    D, H, W, fs = 128, 44, 37, 11
+    H, W, fs = 44, 37, 11
     fsf = O.moffat_cropped(fs, 3.0, 2.5)
     lsf = O.muse_like_lsf(D)
     cube = rng.normal(size=(D, H, W))

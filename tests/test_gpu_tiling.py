@@ -353,9 +353,9 @@ def test_bench_two_ranks_report_the_tiled_leg():
     assert "tiled 2x1" in leg["config"]["parallelism"]
     assert 0.0 < leg["acceptance"] < 1.0
     # the leg verifies itself: gathered parameters == one context given the same parts
-    # (bit for bit where the tiles' own initial residuals are: the one-pass convolution
-    # kernel's depths; else to rounding -- same accepted counts either way)
-    assert leg["bit_identical"] is True or leg["max_abs_param_diff"] <= 1e-9, leg
+    # (bit for bit: at 64 channels the tiles rebuild their residual with the one-pass
+    # convolution kernel, whose sums do not depend on where a tile starts)
+    assert leg["bit_identical"] is True, leg
     assert leg["tiles"] == [2, 1] and leg["phases_per_sweep"] == 2
     assert leg["rccl_ranks"] is None            # gloo rehearsal: no RCCL communicator
     assert leg["halo_ms_per_sweep"] > 0.0
