@@ -246,6 +246,7 @@ int build_colour_lists(d3d_ctx *c) {
                 ++pt.K;
                 pt.last_col = col;
             }
+#ifdef D3D_EXPERIMENTS
         if (!empty && pt.K > 0) {
             const int cus = c->flow_grid / 4;
             const int fhh_ = (c->fh - 1) / 2, fhw_ = (c->fw - 1) / 2;
@@ -269,6 +270,7 @@ int build_colour_lists(d3d_ctx *c) {
                        c->Dp <= pt.chain_ns && lds <= (size_t)160 * 1024 && g_bytes <= 512e6 &&
                        c->cube_elems * sizeof(double) < (size_t(1) << 31);
         }
+#endif
     }
     // device tables of the chain form
     {
@@ -378,6 +380,7 @@ int build_colour_lists(d3d_ctx *c) {
                                hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     pend_clear(c);
+    c->props_sweep = -1;
     return 0;
 }
 
@@ -397,14 +400,13 @@ struct OptDesc {
 const OptDesc g_opts[] = {
     {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer, OPT_MH, 0, 2},
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
-    {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
     {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 40},
+    {"mh_props", "D3D_MH_PROPS", &d3d_ctx::mh_props, OPT_LAUNCH, 0, 1},
     {"halo_timing", "D3D_HALO_TIMING", &d3d_ctx::halo_timing, OPT_LAUNCH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
     {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
     {"mh_nt", "D3D_MH_NT", &d3d_ctx::mh_nt_opt, OPT_MH, 0, 1024},
-    {"mh_maxit", "D3D_MH_MAXIT", &d3d_ctx::mh_maxit_opt, OPT_MH, -1, 32},
     {"uniform_ivar", "D3D_UNIFORM_IVAR", &d3d_ctx::uniform_fast_path, OPT_MH, 0, 1},
     {"conv_rows", "D3D_CONV_ROWS", &d3d_ctx::conv_rows, OPT_LAUNCH, 0, 1},
     {"conv_hy", "D3D_CONV_HY", &d3d_ctx::conv_hy_opt, OPT_LAUNCH, 0, 1 << 20},
@@ -421,6 +423,8 @@ const OptDesc g_opts[] = {
     {"stagger", "D3D_STAGGER", &d3d_ctx::stagger, OPT_LAUNCH, 0, 1 << 20},
 #ifdef D3D_EXPERIMENTS
     // measured-but-not-faster variants of DESIGN.md section 3 (make EXPERIMENTS=1)
+    {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
+    {"mh_maxit", "D3D_MH_MAXIT", &d3d_ctx::mh_maxit_opt, OPT_MH, -1, 32},
     {"mh_flow", "D3D_MH_FLOW", &d3d_ctx::mh_flow, OPT_MH, 0, 1},
     {"mh_pair", "D3D_MH_PAIR", &d3d_ctx::mh_pair, OPT_MH, 0, 1},
     {"spectral_shfl", "D3D_SPECTRAL_SHFL", &d3d_ctx::spectral_shfl, OPT_LAUNCH, 0, 1},
@@ -618,7 +622,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->pair_state, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep,
-                    c->chain_cols, c->chain_flags, c->chain_G};
+                    c->chain_cols, c->chain_flags, c->chain_G, c->props};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -931,6 +935,7 @@ int d3d_set_params(d3d_ctx *c, const double *params) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_params = true;
     c->err_valid = false;
+    c->props_sweep = -1;
     pend_clear(c);
     return D3D_OK;
 }
@@ -1120,6 +1125,7 @@ int d3d_mh_config(d3d_ctx *c, const double min_b[3], const double max_b[3],
     c->seed = seed;
     c->refresh_every = refresh_every;
     c->have_cfg = true;
+    c->props_sweep = -1;
     return D3D_OK;
 }
 
@@ -1127,6 +1133,7 @@ int d3d_mh_set_sweep_origin(d3d_ctx *c, int64_t origin) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(origin >= 0 && origin < (int64_t(1) << 31), D3D_ERR_INVALID, "sweep origin out of range");
     c->sweep_origin = (uint32_t)origin;
+    c->props_sweep = -1;
     return D3D_OK;
 }
 
@@ -1224,9 +1231,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
     if (c->lay_n && (c->pend_part != pi || !deferred))
         if (int rc = flush_pending(c)) return rc;
-    if (deferred && pt.chain) {  // all colours of the part in one launch
-        return launch_mh_chain(c, pi, sweep, 1);
-    }
+#ifdef D3D_EXPERIMENTS
+    if (deferred && pt.chain) return launch_mh_chain(c, pi, sweep, 1);  // all colours in one launch
+#endif
     // two colour classes per launch (k_mh_pair) where the N/W alternation of two pending
     // layers allows it: an unpartitioned context, a launch that fills the chip
     const bool pairs = deferred && c->mh_pair && !partitioned && c->mh_defer == 1 && c->Dp <= 256 &&
@@ -1252,10 +1259,15 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
 #else
         (void)pairs;
 #endif
+        // small colour launches: the sweep's proposals come from one launch before them
+        const bool use_props = c->mh_props && pt.layers == 1 && !c->deep && deferred;
+        if (use_props)
+            if (int rc = ensure_proposals(c, sweep)) return rc;
         d3d::MHArgs P;
         fill_mh_args(c, P);
         P.spx = c->spx + pt.off[col];
         P.rev = (c->mh_zigzag && (ka & 1)) ? 1 : 0;
+        if (use_props) P.props = c->props;
         if (deferred) {
             // real + virtual positions: the windows of this launch tile the domain
             const int n_all = pt.off[col + 1] - pt.off[col];
@@ -1323,6 +1335,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
         if (rc) return rc;
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
+    c->props_sweep = -1;  // a proposal table never outlives the call it was made in
     SnapQueue snaps;
     if (chain_out || dlog_out)
         if (int rc = snap_setup(c)) return rc;
@@ -1334,8 +1347,10 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     // sweep that is saved or followed by a from-scratch residual.
     const bool chain_batches = !flow && !any_plan && c->parts.size() == 1 && c->parts[0].chain &&
                                c->mh_defer == 1 && n_phases == 1;
+    (void)chain_batches;
     for (int s = first_sweep; s < first_sweep + n_sweeps; ++s) {
         const uint32_t rs = (uint32_t)s + c->sweep_origin;
+#ifdef D3D_EXPERIMENTS
         if (chain_batches) {
             int last = first_sweep + n_sweeps - 1;  // last sweep of this launch
             for (int t = s; t <= last; ++t) {
@@ -1350,9 +1365,7 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                 if (int rc = flush_pending(c)) return rc;
             if (int rc = launch_mh_chain(c, 0, rs, last - s + 1)) return rc;
             s = last;
-        } else
-#ifdef D3D_EXPERIMENTS
-        if (flow) {
+        } else if (flow) {
             c->pend_part = 0;
             int rc = launch_mh_flow(c, rs);
             if (rc) return rc;
@@ -1439,6 +1452,7 @@ int d3d_mh_phase(d3d_ctx *c, int phase, int sweep) {
         int rc = d3d_residual(c, nullptr);
         if (rc) return rc;
     }
+    c->props_sweep = -1;  // (recomputed per call: the spaxels not yet updated get the same proposals)
     return run_phase(c, phase, (uint32_t)sweep + c->sweep_origin);
 }
 

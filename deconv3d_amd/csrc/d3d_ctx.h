@@ -162,10 +162,9 @@ struct d3d_ctx {
     int flow_last_cy = -1, flow_last_cx = -1;  // colour class of the last active colour
     // k_mh_pair (two colour classes per launch): per-item flags with epochs and a
     // monotonic ticket counter, so that nothing needs clearing between launches
-    int mh_chain_opt = 0;          // option mh_chain: 1 = k_mh_chain wherever a part's slots are all resident;
-                                   // 0 (default): colour launches -- the chain kernel measures 5-25 % SLOWER
-                                   // (one CU per window is bound by its own VALU and
-                                   // hand-off latencies, not by the kernel boundary it removes)
+    int mh_chain_opt = 0;          // option mh_chain (EXPERIMENTS builds): 1 = k_mh_chain wherever a part's
+                                   // slots are all resident; measured no faster than the colour launches
+                                   // (profiles/r03_chain_phases.txt)
     int2 *chain_cols = nullptr;    // [parts][fh*fw] local residues of each part's active colours
     size_t chain_cols_cap = 0;
     unsigned *chain_flags = nullptr;  // [2][chain_slots_cap]: flag1 | flag2 (monotonic epochs)
@@ -174,6 +173,9 @@ struct d3d_ctx {
     size_t chain_G_cap = 0;
     unsigned chain_base = 0;       // the epoch every flag of a finished launch holds
     bool chain_used = false;       // a chain launch ran since the error word was last read
+    int mh_props = 1;              // option mh_props: the proposals of a sweep in one launch before its colours
+    d3d::MHProposal *props = nullptr;  // [HW]
+    long props_sweep = -1;         // the sweep (Philox number) the table holds, -1 = none
     int mh_prio = 0;               // option mh_prio: staggered completion by wave priority (MHArgs::prio)
     int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
@@ -262,8 +264,12 @@ int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep);
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
                     bool wide);
 int flush_pending(d3d_ctx *c);
+// the proposals of sweep `sweep` for every owned spaxel (MHArgs::props), once per sweep
+int ensure_proposals(d3d_ctx *c, uint32_t sweep);
 // n_sweeps whole sweeps (Philox numbers sweep0 ..) of part pi in one launch (Part::chain)
+#ifdef D3D_EXPERIMENTS
 int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps);
+#endif
 int launch_apply_updates(d3d_ctx *c, const d3d::MHArgs &P, const double *rec, int n);
 int launch_rtnorm(d3d_ctx *c, long n, double lo, double hi, double mu, double sigma, uint64_t seed,
                   int wave_mode, double *buf);

@@ -1498,8 +1498,15 @@ static __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ 
 //   k_mh_flow   k_mh_ws's window code under per-window dependencies, one launch
 //               per sweep (opt-in).
 
+struct MHProposal;
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
+    // Proposals of the whole sweep, [H*W] by local spaxel index, computed by k_mh_proposals
+    // before the sweep's first colour (or NULL: every update makes its own).  A proposal
+    // depends on the spaxel's parameters at the START of the sweep and on its Philox stream
+    // only (lib/run.py:369-388), so the three tan, the log and the two Philox blocks need
+    // not sit on the critical path of a small colour launch (its prepare wavefront).
+    const MHProposal *props;
     double *err;
     const double *ivar;
     double ivar_uniform;  // the constant 1/variance when the cube is uniform (k_mh_ws<.., true>)
@@ -1700,6 +1707,13 @@ __device__ __forceinline__ MHProposal mh_propose(const MHArgs &P, int sp, uint32
                            P.params[(long)sp * 3 + 2], q.gsp, sweep);
 }
 
+// The proposal of an update: taken from the sweep's table when there is one (same function,
+// same arguments, same bits as made here).
+__device__ __forceinline__ MHProposal mh_proposal_of(const MHArgs &P, int sp, uint32_t sweep) {
+    if (P.props && !P.ext_lines && !P.probe) return P.props[sp];
+    return mh_propose(P, sp, sweep);
+}
+
 // LSF-convolved unit lines of channel ch from the zero-extended unit lines in
 // gO / gN (closed form of convolve_1d, lib/convolution.py:89-120).
 __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const double *gN, int ch,
@@ -1874,7 +1888,7 @@ template <int NT>
 __device__ __forceinline__ bool mh_decide(const MHArgs &P, const MHShared &S, int sp,
                                           uint32_t sweep, double *Gz_out) {
     const int tid = threadIdx.x;
-    const MHProposal q = mh_propose(P, sp, sweep);
+    const MHProposal q = mh_proposal_of(P, sp, sweep);
     if (tid < P.N) {
         if (P.ext_lines) {
             const double *L = P.ext_lines + (long)blockIdx.x * 2 * P.D;
@@ -2507,7 +2521,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
         }
     } else if (real) {
         const int lane = tid - NS;
-        const MHProposal q = mh_propose(P, sp, sweep);
+        const MHProposal q = mh_proposal_of(P, sp, sweep);
         for (int j = lane; j < N; j += 64) {
             S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
             S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
@@ -2591,6 +2605,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_run<NS, UV, false, U, M, false, true, NTV>(P, S, I, sweep, blockIdx.x, &pre);
 }
 
+#ifdef D3D_EXPERIMENTS
 // ---- whole sweeps of a small part in ONE launch: persistent workgroups ----------------------
 //
 // A colour launch that does not fill the chip is a latency chain: setup,
@@ -2627,6 +2642,14 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
 //     G-row byte that crosses workgroups is stored write-through (sc1) and loaded sc1; every
 //     storing wavefront drains (vmcnt(0)) and counts itself in LDS, the last one raises the
 //     flag (an sc1 store); every wavefront that loads handed-off bytes polls the flags itself.
+//
+// EXPERIMENTS build only (make EXPERIMENTS=1, option mh_chain = 1).  Measured on MI355X
+// (profiles/r03_chain_phases.txt): 12-14 us per colour class against 12.3 us for one colour
+// launch at 64^3, an 8x1 rank of 300x300x128 3.6 ms per sweep against 3.5 -- it does NOT beat
+// the launches it replaces.  What it removes (the kernel boundary, the window's trip through
+// one CU's memory port) it pays back: one CU does a window's whole arithmetic (11 wavefronts
+// on 4 SIMDs: 3.2 us), the channel sums and the decision (1.7 + 2.3-3.5 us) stay serial per
+// window, and the neighbour's G row reaches the entering column 1.5-5 us after the decision.
 //
 // Window sums are grouped by window COLUMN (the thread group that holds it accumulates its
 // fh rows top to bottom; the columns are then added left to right): another grouping than
@@ -3141,6 +3164,8 @@ __global__ __launch_bounds__(NTMAX) void k_mh_chain(MHArgs P, MHChain F) {
         }
     }
 }
+
+#endif  // D3D_EXPERIMENTS (k_mh_chain)
 
 #ifdef D3D_EXPERIMENTS
 // ---- one launch per sweep: dataflow over the colour classes ----------------
@@ -3762,6 +3787,20 @@ static __global__ __launch_bounds__(1024) void k_mh_deep(MHArgs P, uint32_t swee
             }
         }
     }
+}
+
+// The proposals of one sweep for every unmasked spaxel of the rectangle [y0,y1) x [x0,x1)
+// (MHArgs::props), one thread per spaxel.
+static __global__ __launch_bounds__(256) void k_mh_proposals(MHArgs P, uint32_t sweep, int y0, int y1,
+                                                              int x0, int x1, MHProposal *out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int w = x1 - x0;
+    if (i >= (y1 - y0) * w) return;
+    const int y = y0 + i / w, x = x0 + i % w;
+    const long sp = (long)y * P.W + x;
+    if (!P.mask[sp]) return;
+    out[sp] = mh_propose_from(P, P.params[sp * 3 + 0], P.params[sp * 3 + 1], P.params[sp * 3 + 2],
+                              (uint32_t)((y + P.gy0) * P.Wg + (x + P.gx0)), sweep);
 }
 
 // Halo exchange of the tiled chain: the cells (all E values per spaxel: E = Dp for

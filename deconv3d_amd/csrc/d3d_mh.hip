@@ -51,6 +51,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.spx = c->spx;
     P.rev = 0;
     P.prio = c->mh_prio;
+    P.props = nullptr;  // (run_part sets it for the parts whose colour launches are small)
     for (int k = 0; k < 3; ++k) {
         P.min_b[k] = c->min_b[k];
         P.max_b[k] = c->max_b[k];
@@ -115,13 +116,17 @@ int launch_mh_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep)
 
 template <int NT>
 int launch_mh_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+#ifdef D3D_EXPERIMENTS
+    // register-resident windows (option mh_maxit): measured slower -- occupancy
     switch (c->mh_maxit) {
         case 4: return launch_mh_t<NT, 4>(c, P, grid, sweep);
         case 8: return launch_mh_t<NT, 8>(c, P, grid, sweep);
         case 16: return launch_mh_t<NT, 16>(c, P, grid, sweep);
         case 32: return launch_mh_t<NT, 32>(c, P, grid, sweep);
-        default: return launch_mh_t<NT, 0>(c, P, grid, sweep);
+        default: break;
     }
+#endif
+    return launch_mh_t<NT, 0>(c, P, grid, sweep);
 }
 
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
@@ -364,6 +369,21 @@ int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
     }
 }
 
+int ensure_proposals(d3d_ctx *c, uint32_t sweep) {
+    if (c->props_sweep == (long)sweep) return 0;
+    if (!c->props) HIP_TRY(hipMalloc(&c->props, (size_t)c->HW * sizeof(d3d::MHProposal)));
+    d3d::MHArgs P;
+    fill_mh_args(c, P);
+    const int n = (c->oy1 - c->oy0) * (c->ox1 - c->ox0);
+    if (n > 0) {
+        hipLaunchKernelGGL(d3d::k_mh_proposals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           P, sweep, c->oy0, c->oy1, c->ox0, c->ox1, c->props);
+        HIP_TRY(hipGetLastError());
+    }
+    c->props_sweep = (long)sweep;
+    return 0;
+}
+
 // Write the pending (deferred) residual updates into SLOT_ERR.
 int flush_pending(d3d_ctx *c) {
     if (c->lay_n == 0) return 0;
@@ -388,6 +408,7 @@ int flush_pending(d3d_ctx *c) {
 }
 
 
+#ifdef D3D_EXPERIMENTS
 // ---- k_mh_chain: whole sweeps of a small part in one launch --------------------------------
 namespace {
 // Chain kernels of different contexts of one process must not share the chip: each needs
@@ -487,6 +508,8 @@ int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps) {
     c->pend_part = pi;
     return 0;
 }
+
+#endif  // D3D_EXPERIMENTS
 
 int launch_apply_updates(d3d_ctx *c, const d3d::MHArgs &P, const double *rec, int n) {
     const size_t lds = (size_t)(2 * c->N + c->Dp) * sizeof(double);

@@ -358,9 +358,12 @@ int launch_spatial_nt(d3d_ctx *c, const double *in, double *out, const double *d
 bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     if (!c->conv_rows) return false;
     if (!(c->fsf_symx && c->fsf_symy && c->fh == c->fw)) return false;
-    if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D)) return false;
-    if (c->Dp == 64 || c->Dp == 32)  // several spectra per wavefront: the BASELINE footprints
-        return c->fw == 9 || c->fw == 11;
+    // (the LSF epilogue is built for mirror-symmetric taps only -- every Gaussian / MUSE-like
+    // LSF; an asymmetric one gets its own pass)
+    if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D && c->lsf_dense_sym)) return false;
+    if (c->Dp == 64 || c->Dp == 32)  // several spectra per wavefront: the BASELINE footprints,
+        return (c->fw == 9 || c->fw == 11) &&
+               (c->fsf_symt || (c->fsf_sep && c->march_mode > 0));  // radial or outer-product FSFs
     if (c->Dp != d3d::CONV_DP) return false;
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: return true;
@@ -400,12 +403,9 @@ int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *
 
 template <int FS, int TSYM, int DPS = d3d::CONV_DP>
 int launch_conv_rows_ts(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    const bool sym = c->lsf_dense_sym;
-    if (lsf) {
-        if (data) return sym ? launch_conv_rows_t<FS, true, true, true, TSYM, DPS>(c, in, out, data)
-                             : launch_conv_rows_t<FS, true, false, true, TSYM, DPS>(c, in, out, data);
-        return sym ? launch_conv_rows_t<FS, true, true, false, TSYM, DPS>(c, in, out, data)
-                   : launch_conv_rows_t<FS, true, false, false, TSYM, DPS>(c, in, out, data);
+    if (lsf) {  // (conv_rows_usable: symmetric LSF taps)
+        if (data) return launch_conv_rows_t<FS, true, true, true, TSYM, DPS>(c, in, out, data);
+        return launch_conv_rows_t<FS, true, true, false, TSYM, DPS>(c, in, out, data);
     }
     if (data) return launch_conv_rows_t<FS, false, false, true, TSYM, DPS>(c, in, out, data);
     return launch_conv_rows_t<FS, false, false, false, TSYM, DPS>(c, in, out, data);
@@ -415,7 +415,8 @@ template <int FS, int DPS = d3d::CONV_DP>
 int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
     if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2, DPS>(c, in, out, data, lsf);
     if (c->fsf_symt) return launch_conv_rows_ts<FS, 1, DPS>(c, in, out, data, lsf);
-    return launch_conv_rows_ts<FS, 0, DPS>(c, in, out, data, lsf);
+    if constexpr (DPS == d3d::CONV_DP) return launch_conv_rows_ts<FS, 0, DPS>(c, in, out, data, lsf);
+    return fail(D3D_ERR_STATE, "internal: no one-pass kernel for this FSF at %d channels", c->Dp);
 }
 
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {

@@ -21,7 +21,10 @@ from oracle import deconv3d_oracle as O
 from tests.cases import make_case
 from tests.tiling_oracle import sweep_in_part_order
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not _lib.has_experiments() if _lib.device_count() else True,
+                                 reason="k_mh_chain is only in a `make EXPERIMENTS=1` build "
+                                        "(tools/build_experiments.sh; DECONV3D_HIP_LIB=...)")]
 
 
 def run(case, chain, sweeps=3, per_call=None, lay=None, uniform=False, keep=None, extra=None):

@@ -89,7 +89,7 @@ def test_config4_partitioned_sweep_in_part_order_against_the_oracle():
     lay = tiling.TileLayout(300, 300, 11, 11, 8, 1)
     outs = []
     for wide in (1, 0):
-        eng, pb = build(128, 300, 300, 11, options={"mh_wide": wide, "mh_chain": 0})
+        eng, pb = build(128, 300, 300, 11, options={"mh_wide": wide})
         with eng:
             tiling.apply_parts(eng, lay)
             err0 = start(eng, pb)
@@ -115,7 +115,7 @@ def test_beyond_cache_policy_is_bit_identical_and_matches_the_oracle():
     same results as the default policy -- and both equal the oracle."""
     outs = []
     for nt in (0, 1):
-        eng, pb = build(16, 300, 300, 11, options={"mh_nt_ivar": nt, "mh_chain": 0})
+        eng, pb = build(16, 300, 300, 11, options={"mh_nt_ivar": nt})
         with eng:
             assert eng.mh_layers() == 2          # chip-filling launches: the NTV kernels' family
             assert eng.get_option("mh_nt_ivar") == nt

@@ -219,12 +219,13 @@ def test_write_back_schemes_are_bit_identical(name):
     case = make_case(name)
     outs = []
     from deconv3d_amd import _lib
-    variants = [{"mh_defer": 1}, {"mh_defer": 1, "mh_layers": 1}, {"mh_defer": 1, "mh_layers": 2},
-                {"mh_defer": 1, "mh_layers": 3}, {"mh_defer": 1, "mh_chain": 0}, {"mh_defer": 2},
-                {"mh_defer": 0, "mh_maxit": 0},
-                {"mh_defer": 0, "mh_maxit": 8}]   # same workgroup size: same summation order
-    if _lib.has_experiments():   # k_mh_pair / k_mh_flow: only in a `make EXPERIMENTS=1` build
-        variants += [{"mh_defer": 1, "mh_layers": 2, "mh_pair": 1}, {"mh_defer": 1, "mh_flow": 1}]
+    variants = [{"mh_defer": 1}, {"mh_defer": 1, "mh_props": 0}, {"mh_defer": 1, "mh_layers": 1},
+                {"mh_defer": 1, "mh_layers": 2},
+                {"mh_defer": 1, "mh_layers": 3}, {"mh_defer": 2},
+                {"mh_defer": 0}]
+    if _lib.has_experiments():   # k_mh_pair / k_mh_flow / register-resident k_mh: `make EXPERIMENTS=1`
+        variants += [{"mh_defer": 1, "mh_layers": 2, "mh_pair": 1}, {"mh_defer": 1, "mh_flow": 1},
+                     {"mh_defer": 0, "mh_maxit": 8}]   # same workgroup size: same summation order
     for opts in variants:
         with engine_for(case, options=opts) as eng:
             eng.set_params(case["init"])
@@ -309,3 +310,24 @@ def test_residual_refresh_keeps_chain_consistent():
         fresh = eng.residual()
     scale = np.max(np.abs(fresh))
     assert np.max(np.abs(carried - fresh)) <= 1e-11 * scale
+
+
+def test_proposal_table_is_rebuilt_for_every_call():
+    """Option mh_props: the proposals of a sweep come from one launch before its colour
+    launches.  The table never outlives a call: the same sweep number run twice in a row
+    (from the state the first run left) and per-phase stepping give the same bits with the
+    table as without it."""
+    from deconv3d_amd import _lib
+    case = make_case("moffat")
+    outs = []
+    for props in (1, 0):
+        with engine_for(case, options={"mh_props": props}) as eng:
+            eng.set_params(case["init"])
+            eng.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=5, refresh_every=0)
+            eng.mh_sweeps(1, 1)
+            eng.mh_sweeps(1, 1)          # sweep number 1 again, other parameters now
+            eng.mh_phase(0, 2)           # d3d_mh_phase: one call per phase
+            eng.mh_sweeps(2, 3)
+            outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog()))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
