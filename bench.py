@@ -397,6 +397,9 @@ def main():
                     help="skip the legs beside the contract line (beyond-MALL cube, uniform "
                          "variance, Gaussian FSF, reference-layout convolution)")
     ap.add_argument("--conv-iters", type=int, default=50)
+    ap.add_argument("--no-conv-beyond-mall", action="store_true",
+                    help="skip the 600x600x128 convolution leg (tools/profile_round.sh: it runs the "
+                         "same kernel as `roofline_conv` and would mix into its counter averages)")
     ap.add_argument("--tiles", default=None,
                     help="--mode tiled: tile grid TYxTX (default: row strips, N x 1); with "
                          "--gpus 1 the tiles run as contexts of this one process (loop-back)")
@@ -581,7 +584,7 @@ def main():
         eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
     slots_ms = eng.timer_stop() / max(args.conv_iters, 1)
     roofline_conv = conv_entry(slots_ms, "k_conv_rows (LSF x FSF in one pass, slot layout)",
-                               "k_conv_rows<11, 15, true, true, false, 1>")
+                               "k_conv_rows<11, 15, true, true, false, 1,")
     roofline_conv["algorithmic_bytes"] = conv_bytes
     roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
                                           "k_spatial_z")
@@ -636,7 +639,8 @@ def main():
         out["host"] = host_info()
     if rank == 0 and not args.no_extras and args.workload == "c3_300x300x128":
         out["roofline_beyond_mall"] = beyond_mall_leg(args, local_rank, fs)
-        out["roofline_conv_beyond_mall"] = conv_beyond_mall_leg(args, local_rank, fs)
+        if not args.no_conv_beyond_mall:
+            out["roofline_conv_beyond_mall"] = conv_beyond_mall_leg(args, local_rank, fs)
     if rank == 0 and not args.no_extras:
         # the reference's default variance (Run(variance=None): one constant,
         # lib/run.py:171-178): the MH kernel does not read SLOT_IVAR at all
@@ -677,7 +681,7 @@ def main():
             g_ms = eng.timer_stop() / max(args.conv_iters, 1)
             out["roofline_conv_gaussian"] = conv_entry(
                 g_ms, "k_conv_rows, outer-product form (Gaussian 11x11 FSF; LSF in the same pass)",
-                "k_conv_rows<11, 15, true, true, false, 2>")
+                "k_conv_rows<11, 15, true, true, false, 2,")
             out["roofline_conv_gaussian"]["fp64_tflops"] = round(
                 2.0 * (fh + fw + ntaps_lsf) * D * H * W / (g_ms * 1e-3) / 1e12, 2)
             out["roofline_conv_gaussian"].pop("fp64_frac", None)

@@ -401,7 +401,6 @@ const OptDesc g_opts[] = {
     {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer, OPT_MH, 0, 2},
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
-    {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 40},
     {"mh_props", "D3D_MH_PROPS", &d3d_ctx::mh_props, OPT_LAUNCH, 0, 1},
     {"halo_timing", "D3D_HALO_TIMING", &d3d_ctx::halo_timing, OPT_LAUNCH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
@@ -424,6 +423,7 @@ const OptDesc g_opts[] = {
 #ifdef D3D_EXPERIMENTS
     // measured-but-not-faster variants of DESIGN.md section 3 (make EXPERIMENTS=1)
     {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
+    {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 40},
     {"mh_maxit", "D3D_MH_MAXIT", &d3d_ctx::mh_maxit_opt, OPT_MH, -1, 32},
     {"mh_flow", "D3D_MH_FLOW", &d3d_ctx::mh_flow, OPT_MH, 0, 1},
     {"mh_pair", "D3D_MH_PAIR", &d3d_ctx::mh_pair, OPT_MH, 0, 1},

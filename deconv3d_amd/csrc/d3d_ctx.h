@@ -82,7 +82,7 @@ struct d3d_ctx {
         int dy0 = 0, dy1 = 0, dx0 = 0, dx1 = 0;  // domain (local)
         int phase = 0;
         int layers = 1;                          // pending layers in use
-        bool wide = false;                       // its colour launches take the 960-thread form
+        bool wide = false;                       // its colour launches take the wide form (MH_WIDE_NS)
         // k_mh_chain (whole sweeps of the part in one launch): slot grid, or chain = false
         bool chain = false;
         int chain_ns = 0, chain_sx0 = 0, n_sy = 0, n_sx = 0, K = 0;
@@ -177,7 +177,7 @@ struct d3d_ctx {
     d3d::MHProposal *props = nullptr;  // [HW]
     long props_sweep = -1;         // the sweep (Philox number) the table holds, -1 = none
     int mh_prio = 0;               // option mh_prio: staggered completion by wave priority (MHArgs::prio)
-    int mh_wide = 1;               // D3D_MH_WIDE=0: never the 960-thread form for the small launches of a partitioned context
+    int mh_wide = 1;               // option mh_wide = 0: never the wide form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)
     unsigned *pair_state = nullptr;  // [0] ticket counter | [4 ..] done flags per item

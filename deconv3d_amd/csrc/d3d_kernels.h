@@ -1501,12 +1501,6 @@ static __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ 
 struct MHProposal;
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
-    // Proposals of the whole sweep, [H*W] by local spaxel index, computed by k_mh_proposals
-    // before the sweep's first colour (or NULL: every update makes its own).  A proposal
-    // depends on the spaxel's parameters at the START of the sweep and on its Philox stream
-    // only (lib/run.py:369-388), so the three tan, the log and the two Philox blocks need
-    // not sit on the critical path of a small colour launch (its prepare wavefront).
-    const MHProposal *props;
     double *err;
     const double *ivar;
     double ivar_uniform;  // the constant 1/variance when the cube is uniform (k_mh_ws<.., true>)
@@ -1550,10 +1544,6 @@ struct MHArgs {
     // cube's working set exceeds it (300x300x256: 96.8 -> 83.7 us per launch).  The window
     // sums are then accumulated in that order, in every kernel alike.
     int rev;
-    // Staggered completion (option mh_prio, default 0 = off; mh_stagger): half of a
-    // colour's windows finish streaming before the other half, so that their decisions
-    // overlap the others' streams (measured flat: DESIGN.md section 3).
-    int prio;
     int lay_cy[3], lay_cx[3];
     const double *lay_G[3];
     int prev_cy, prev_cx; // colour class of the pending updates, -1 = none
@@ -1575,6 +1565,16 @@ struct MHArgs {
     int probe_sp;
     double probe_p[3];
     double *probe_out;
+    // Proposals of the whole sweep, [H*W] by local spaxel index, computed by k_mh_proposals
+    // before the sweep's first colour (or NULL: every update makes its own).  A proposal
+    // depends on the spaxel's parameters at the START of the sweep and on its Philox stream
+    // only (lib/run.py:369-388), so the three tan, the log and the two Philox blocks need
+    // not sit on the critical path of a small colour launch (its prepare wavefront).
+    const MHProposal *props;
+    // Staggered completion (EXPERIMENTS builds, option mh_prio; mh_stagger): half of a
+    // colour's windows finish streaming before the other half, so that their decisions
+    // overlap the others' streams (measured flat: DESIGN.md section 3).
+    int prio;
 #ifdef D3D_EXPERIMENTS
     // k_mh_ws phase stamps (100 MHz wall clock), 8 slots per workgroup: 0 entry,
     // 1 setup done, 2 window streamed, 3 prepare wavefront done, 4 update written
@@ -1597,6 +1597,8 @@ constexpr int MH_LAYERS = 3;  // pending colours k_mh_ws can apply in one pass
 // Staggered completion (MHArgs::prio; measured flat): 1..15 -- the
 // workgroups with bit prio-1 of their index set run at raised wave priority; 16 + n -- the
 // odd workgroups start n x 0.8 us late.
+// EXPERIMENTS builds only: even the untaken test costs the default kernel 0.7 us per launch
+// (the launch's first instructions wait for one more kernel argument).
 __device__ __forceinline__ void mh_stagger(int prio) {
     if (prio <= 0) return;
     if (prio < 16) {
@@ -2392,7 +2394,10 @@ __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &
     }
 }
 
-template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false, bool NTV = false>
+// PROPS: the launch may take its proposals from the sweep's table (MHArgs::props; the small
+// launches' variants only: the others keep the table out of their code).
+template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false, bool NTV = false,
+          bool PROPS = false>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                           uint32_t sweep, long stamp_at,
                                           const MHPre<U> *pre = nullptr) {
@@ -2521,7 +2526,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
         }
     } else if (real) {
         const int lane = tid - NS;
-        const MHProposal q = mh_proposal_of(P, sp, sweep);
+        const MHProposal q = PROPS ? mh_proposal_of(P, sp, sweep) : mh_propose(P, sp, sweep);
         for (int j = lane; j < N; j += 64) {
             S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
             S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
@@ -2576,7 +2581,9 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     constexpr int NT = NS + 64;
     const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
     D3D_MH_STAMP(blockIdx.x, 0, 0);
+#ifdef D3D_EXPERIMENTS
     mh_stagger(P.prio);
+#endif
     const int4 ent = P.spx[blockIdx.x];
     MHWsItem I;
     I.y = ent.x;  // may lie outside the cube when virtual
@@ -2602,7 +2609,9 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
-    mh_ws_run<NS, UV, false, U, M, false, true, NTV>(P, S, I, sweep, blockIdx.x, &pre);
+    // (U = 4 or the wide form: the variants of launches that do not fill the chip)
+    mh_ws_run<NS, UV, false, U, M, false, true, NTV, (U == 4 || NS != 256)>(P, S, I, sweep, blockIdx.x,
+                                                                           &pre);
 }
 
 #ifdef D3D_EXPERIMENTS
@@ -3378,7 +3387,9 @@ __global__ __launch_bounds__(NS + 64) void k_mh_pair(MHArgs P, MHPair F, uint32_
     // the host reports it instead of hanging.
     const int t = (int)blockIdx.x;
     if (t >= F.n_a + F.n_b) return;
+#ifdef D3D_EXPERIMENTS
     mh_stagger(P.prio);
+#endif
     const bool is_b = t >= F.n_a;
     const int item = is_b ? F.first_b + (t - F.n_a) : F.first_a + t;
     const int4 ent = F.ent[item];

@@ -204,8 +204,8 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
     // against 40.8 with two for both.  Round 2, for launches that do not fill the
     // chip: EIGHT positions in flight measured slower than four -- a 150x300 tile part 6.41
-    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); fifteen
-    // streaming wavefronts per window: see the 960-thread form below)
+    // vs 5.26 ms per sweep, 32x16x16 10.45 vs 9.95 us per launch (165-175 VGPRs); more
+    // streaming wavefronts per window: see the wide form below)
     // (1/variance with the non-temporal hint when the context's working set exceeds the
     // Infinity Cache: mh_load_ivar; only the chip-filling launches have the variant)
     if constexpr (!UV) {
@@ -232,19 +232,19 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     }
     // The small launches of a PARTITIONED context (tiles, d3d_set_parts) at 128 channels: a
     // launch of at most one workgroup per CU is bound by how fast ONE workgroup gets through
-    // its window (121 positions through four wavefronts, ~1 us per round trip), so fifteen
-    // streaming wavefronts instead of four (k_mh_ws<960>, ONE position in flight per
-    // wavefront: 3.52 ms against 3.61 with two and 3.77 with four): an 8x1 rank of
-    // 300x300x128 4.18 -> 3.52 ms per sweep.  (What then bounds such a launch, by the phase
+    // its window (121 positions through four wavefronts, ~1 us per round trip), so eleven
+    // streaming wavefronts instead of four (k_mh_ws<MH_WIDE_NS = 704>, one per window row of an
+    // 11 x 11 FSF, ONE position in flight per wavefront): an 8x1 rank of 300x300x128
+    // 4.18 -> 3.48 ms per sweep (round 2's fifteen wavefronts, k_mh_ws<960>: 3.52; two / four
+    // positions in flight: 3.61 / 3.77).  (What then bounds such a launch, by the phase
     // stamps: setup 2.3 us, the prepare wavefront's proposal -> line -> LSF chain 6.4, the
     // decision tail 4.5, the kernel boundary 2.4; a second prepare wavefront for the
     // current line gained 1.5 %: not kept.)  Another grouping of the window sums than the 256-thread form
     // (results agree to rounding, not bit for bit), hence only where nothing is compared bit for
     // bit with another scheme: a given part always takes the same form, so a tiled chain and
     // the single context given the same parts still agree to the last bit.  Shallow cubes lose
-    // (32 channels: 9.9 -> 12.2 us per launch).  D3D_MH_WIDE=0: off.
-    // (decided per PART, Part::wide, so that every colour of a part -- and the chain kernel
-    // that replaces its launches -- groups the window sums alike)
+    // (32 channels: 9.9 -> 12.2 us per launch).  Option mh_wide = 0: off.
+    // (decided per PART, Part::wide, so that every colour of a part groups the window sums alike)
     if (small && wide) return launch_mh_ws_um<UV, 1, 1, 1, false, MH_WIDE_NS>(c, P, grid, sweep);
     if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);

@@ -36,8 +36,8 @@ one-GPU rehearsal and the bit-identity tests); host-staged torch.distributed
 
 What this buys -- measured, DESIGN.md section 7: the colour classes of a part are a
 dependent chain of fh*fw launches, and a launch that does not fill the chip costs
-~14 us at 128 channels however few windows it holds (fifteen streaming wavefronts per
-window, k_mh_ws<960>; 17 us with four).  One interior rank of an 8 x 1 tiling of
+~14 us at 128 channels however few windows it holds (eleven streaming wavefronts per
+window, k_mh_ws<704>; 17 us with four).  One interior rank of an 8 x 1 tiling of
 300x300x128 computes 3.5 ms per sweep alone against 4.9 ms for the whole cube on one
 GPU: the tiled chain is the mode for a cube or a chain that must be SPLIT
 (or one much larger than 300x300: at 900x900x128 a rank of 8 x 1 computes 7.2 ms against

@@ -5,8 +5,9 @@ those shapes are compared with the CPU restatement itself, not only with each ot
 
   * config 3, 300x300x128, default kernel selection (k_mh_ws with two pending layers,
     zig-zag walk, virtual border positions);
-  * the same cube partitioned for 8x1 ranks, in part order: the 960-thread form of the
-    small colour launches (k_mh_ws<960>), and that form against the 256-thread one;
+  * the same cube partitioned for 8x1 ranks, in part order: the wide form of the small
+    colour launches (k_mh_ws<704>: eleven streaming wavefronts per window), and that form
+    against the 256-thread one;
   * a chip-filling cube with the beyond-the-Infinity-Cache policy forced on
     (non-temporal 1/variance loads, write-through residual stores) against the
     default policy, bit for bit, and against the oracle;
@@ -83,7 +84,7 @@ def test_config3_full_sweep_update_by_update_against_the_oracle():
 def test_config4_partitioned_sweep_in_part_order_against_the_oracle():
     """The 300x300x128 cube with the parts of an 8x1 tiling on one context (the scan
     order a tiled chain has, tiling.apply_parts): its small colour launches run the
-    960-thread form.  One sweep against the oracle in (phase, part, colour) order; then
+    wide form (eleven streaming wavefronts per window).  One sweep against the oracle in (phase, part, colour) order; then
     the 256-thread form (option mh_wide = 0) must agree to rounding -- another grouping
     of the window sums, not another algorithm."""
     lay = tiling.TileLayout(300, 300, 11, 11, 8, 1)

@@ -84,7 +84,7 @@ with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as fh:
 with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
     fh.write("# rocprofv3 summary %s\n\n" % tag)
     fh.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 "
-             "--no-cpu --conv-iters 10` (+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
+             "--no-cpu --conv-iters 10 --no-conv-beyond-mall` (+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
              "`--pmc TCC_HIT_sum TCC_MISS_sum` passes)\n\n")
     fh.write("HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB.  "
              "`k_mh_ws<..., *>` rows: launch-weighted mean over the kernel's pending-layer variants "
