@@ -2275,6 +2275,11 @@ template <int M, int K, bool COH>
 __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
                                               MHGpRegs<M, K> &R) {
     const int Dp = P.Dp;
+    // (one scalar register for all K loads: left to itself the compiler re-fetches the kernel
+    // argument in front of every one of them -- four dependent scalar loads in the setup of a
+    // small launch, 0.6 us per launch at 64 channels)
+    int slots_x = P.slots_x;
+    asm volatile("" : "+s"(slots_x));
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const int py0 = I.psy0[j], py1 = I.psy1[j], px0 = I.psx0[j], px1 = I.psx1[j];
@@ -2288,7 +2293,7 @@ __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I
                 const int sx = (q & 1) ? px1 : px0;
                 if (sy >= 0 && sx >= 0) {
                     const double *src =
-                        I.lay_G[j] + ((long)(sy / P.fh) * P.slots_x + sx / P.fw) * Dp + z;
+                        I.lay_G[j] + ((long)(sy / P.fh) * slots_x + sx / P.fw) * Dp + z;
                     if (COH)
                         R.v[j][k] = __longlong_as_double((long long)__hip_atomic_load(
                             reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
