@@ -331,3 +331,46 @@ def test_proposal_table_is_rebuilt_for_every_call():
             outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog()))
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_options_belong_to_a_context_not_to_the_process(monkeypatch):
+    """VERDICT r2 item 8 on the default build: three contexts of one process with different
+    kernel families, alive together and stepped in turn, each keep their own setting and
+    produce the same chain bit for bit; an option can change between calls (pending
+    layers are flushed); the environment only supplies the default of a NEW context."""
+    from deconv3d_amd import _lib
+    case = make_case("c1")
+    engs = []
+    for opts in ({"mh_layers": 2}, {"mh_layers": 3}, {"mh_defer": 0}):
+        e = engine_for(case, options=opts)
+        e.set_params(case["init"])
+        e.mh_config(case["min_b"], case["max_b"], 0.1, 50.0, seed=5, refresh_every=0)
+        engs.append(e)
+    try:
+        assert [e.get_option("mh_defer") for e in engs] == [1, 1, 0]
+        assert [e.mh_layers() for e in engs][:2] == [2, 3]
+        for s in (1, 2, 3):
+            for e in engs:
+                e.mh_sweeps(1, s)
+        engs[1].set_option("mh_layers", 1)           # mid-chain: flushes what is pending
+        assert engs[1].mh_layers() == 1 and engs[0].mh_layers() == 2
+        for e in engs:
+            e.mh_sweeps(1, 4)
+        outs = [(e.get_params(), e.download_slot(_lib.SLOT_ERR)) for e in engs]
+        for other in outs[1:]:
+            np.testing.assert_array_equal(other[0], outs[0][0])
+            np.testing.assert_array_equal(other[1], outs[0][1])
+        with pytest.raises(ValueError):
+            engs[0].set_option("no_such_option", 1)
+        with pytest.raises(ValueError):
+            engs[0].set_option("mh_layers", 7)
+        # the environment: a default for contexts created afterwards, nothing more
+        monkeypatch.setenv("D3D_MH_DEFER", "2")
+        assert engs[0].get_option("mh_defer") == 1
+        with engine_for(case) as late:
+            assert late.get_option("mh_defer") == 2
+        with engine_for(case, options={"mh_defer": 0}) as late:
+            assert late.get_option("mh_defer") == 0
+    finally:
+        for e in engs:
+            e.close()
