@@ -408,6 +408,7 @@ const OptDesc g_opts[] = {
     {"mh_nt", "D3D_MH_NT", &d3d_ctx::mh_nt_opt, OPT_MH, 0, 1024},
     {"uniform_ivar", "D3D_UNIFORM_IVAR", &d3d_ctx::uniform_fast_path, OPT_MH, 0, 1},
     {"conv_rows", "D3D_CONV_ROWS", &d3d_ctx::conv_rows, OPT_LAUNCH, 0, 1},
+    {"conv_zb", "D3D_CONV_ZB", &d3d_ctx::conv_zb, OPT_LAUNCH, 0, 1},
     {"conv_hy", "D3D_CONV_HY", &d3d_ctx::conv_hy_opt, OPT_LAUNCH, 0, 1 << 20},
     {"spatial_sep", "D3D_SPATIAL_SEP", &d3d_ctx::spatial_sep, OPT_TAPS, 0, 1},
     {"sep_fuse", "D3D_SEP_FUSE", &d3d_ctx::sep_fuse, OPT_LAUNCH, 0, 1},

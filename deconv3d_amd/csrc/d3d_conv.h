@@ -35,6 +35,7 @@ struct ConvRowsArgs {
     int H, W, HY;  // cube rows / columns, output rows per strip
     int ngx, ngy;  // column groups, row strips
     int xcd_remap;
+    int Dp;        // ZB: the cube's padded depth = column stride in doubles (any even number)
 };
 // The tap tables come as separate `const double *__restrict__` kernel arguments (not
 // inside the struct): only then does the compiler know that nothing this kernel stores
@@ -57,6 +58,15 @@ constexpr int CONV_NBUF = 4;  // LDS ring of input rows: two PAIRS (one read, on
 // g = lane / (DPS/2) the column x + g.  Adjacent spectra are adjacent in memory and in the
 // LDS rows, so a wavefront's 1 KiB accesses stay contiguous and the stencil's column
 // offsets become multiples of DPS doubles instead of 128.
+//
+// ZB (round 3, any depth above 128, FSF only): the spectrum is cut into Z-BLOCKS of 128
+// channels and a workgroup takes one block of its column group (grid = z-blocks x row strips
+// x column groups).  The FSF acts channel by channel, so the blocks are independent; the
+// kernel is the 128-channel one with the column stride (A.Dp doubles) and the block's channel
+// offset as run-time numbers, and a lane predicate for the ragged last block (a lane whose
+// z-pair lies beyond Dp never loads -- its LDS slots keep the zero written at the start -- and
+// never stores).  The LSF couples channels across blocks: it is applied by the line kernel
+// (forward model) or by its own pass (an arbitrary cube), never here.
 template <int FS, int NW, int DPS>
 struct ConvGeo {
     static constexpr int SPW = CONV_DP / DPS;                        // spectra per wavefront
@@ -90,9 +100,9 @@ __device__ __forceinline__ void conv_glds16(const double *gsrc, double *lds_dst)
 // when tap rows FHH-a / FHH+a reach an output row of the strip at all: that skips the
 // dot products of the first and last FHH steps (10 % of a strip's FMAs) for one scalar
 // bit test each.
-template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH, int DPS>
-__device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long rowstride, int x,
-                                               bool xok, int wave, int lane, const double *rows,
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int PH, int DPS, bool ZB>
+__device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long rowstride, int cstride,
+                                               int x, bool xok, int wave, int lane, const double *rows,
                                                double *myspec,
                                                const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
                                                const double (&w)[2 * LSF_RL + 1],
@@ -117,7 +127,7 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
         // one step ahead: the data row of the output finished by step i+1
         if (xok && oy + 1 >= y0 && oy + 1 < yend)
             dnext = *reinterpret_cast<const double2 *>(data + (long)(oy + 1) * rowstride +
-                                                       (long)x * DP + 2 * zl);
+                                                       (long)x * (ZB ? cstride : DP) + 2 * zl);
     }
     {
         const double *rb = rows + (size_t)(i % NBUF) * RBUF + (size_t)wave * CONV_DP + 2 * lane;
@@ -215,16 +225,18 @@ __device__ __forceinline__ void conv_rows_step(int i, int y0, int yend, long row
             v.x = dcur.x - v.x;
             v.y = dcur.y - v.y;
         }
-        double2 *dst = reinterpret_cast<double2 *>(out + (long)oy * rowstride + (long)x * DP + 2 * zl);
+        double2 *dst = reinterpret_cast<double2 *>(out + (long)oy * rowstride +
+                                                   (long)x * (ZB ? cstride : DP) + 2 * zl);
         if (xok) *dst = v;
     }
 }
 
 // FS consecutive steps starting at step `base` (base mod FS == 0), a workgroup barrier
 // before every even step: input rows travel in PAIRS (see the loader).
-template <int FS, int NW, bool LSF, bool RESID, bool SEP, int DPS, int PH = 0>
+template <int FS, int NW, bool LSF, bool RESID, bool SEP, int DPS, bool ZB, int PH = 0>
 __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, int yend,
-                                                long rowstride, int x, bool xok, int wave, int lane,
+                                                long rowstride, int cstride, int x, bool xok, int wave,
+                                                int lane,
                                                 const double *rows, double *myspec,
                                                 const double (&q)[(FS + 1) / 2][(FS + 1) / 2],
                                                 const double (&w)[2 * LSF_RL + 1],
@@ -236,26 +248,28 @@ __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, in
         if (i < nsteps) {
             // (every LDS read of the previous pair has been consumed: data dependences)
             if ((i & 1) == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            conv_rows_step<FS, NW, LSF, RESID, SEP, PH, DPS>(i, y0, yend, rowstride, x, xok, wave, lane,
-                                                             rows, myspec, q, w, data, out, ring, dnext);
+            conv_rows_step<FS, NW, LSF, RESID, SEP, PH, DPS, ZB>(i, y0, yend, rowstride, cstride, x, xok,
+                                                                 wave, lane, rows, myspec, q, w, data,
+                                                                 out, ring, dnext);
             // keep the steps apart: interleaving two of them costs more registers than the
             // 128 that four wavefronts per SIMD allow
             __builtin_amdgcn_sched_barrier(0);
         }
-        conv_rows_steps<FS, NW, LSF, RESID, SEP, DPS, PH + 1>(base, nsteps, y0, yend, rowstride, x, xok,
-                                                              wave, lane, rows, myspec, q, w, data, out,
-                                                              ring, dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, SEP, DPS, ZB, PH + 1>(base, nsteps, y0, yend, rowstride, cstride,
+                                                                  x, xok, wave, lane, rows, myspec, q, w,
+                                                                  data, out, ring, dnext);
     }
 }
 
 // TSYM = 2 selects the outer-product form (SEP): quad holds v[e] (row 0) and u[a] (row 1).
-template <int FS, int NW, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = CONV_DP>
+template <int FS, int NW, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = CONV_DP, bool ZB = false>
 __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                                                               const double *__restrict__ in,
                                                               double *__restrict__ out,
                                                               const double *__restrict__ quad,
                                                               const double *__restrict__ wl,
                                                               const double *__restrict__ data) {
+    static_assert(!ZB || (DPS == CONV_DP && !LSF), "z-blocks: 128-channel blocks, FSF only");
     constexpr int FHH = (FS - 1) / 2, NQ = FHH + 1, DP = DPS;
     constexpr int NBUF = CONV_NBUF, RL = LSF_RL;
     using Geo = ConvGeo<FS, NW, DPS>;
@@ -272,12 +286,22 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
         const int nb = gridDim.x, qq = nb / 8, rm = nb % 8, xcd = blk % 8;
         blk = (xcd < rm ? xcd * (qq + 1) : rm * (qq + 1) + (xcd - rm) * qq) + blk / 8;
     }
+    // ZB: z-block slowest -- the x-neighbours of one block and strip stay neighbours
+    const int zb = ZB ? blk / (A.ngx * A.ngy) : 0;
+    if (ZB) blk -= zb * (A.ngx * A.ngy);
     const int gy = blk / A.ngx, gx = blk - gy * A.ngx;
     const int x0 = gx * NWC, y0 = gy * A.HY;
     const int yend = min(y0 + A.HY, A.H);
     const int nsteps = (yend - y0) + 2 * FHH;
     const int npairs = (nsteps + 1) / 2;
-    const long rowstride = (long)A.W * DP;
+    const int cstride = ZB ? A.Dp : DP;               // doubles between adjacent columns
+    const long rowstride = (long)A.W * cstride;
+    const bool zok = !ZB || zb * CONV_DP + 2 * lane < A.Dp;  // (Dp is even: a z-pair is in or out)
+    if (ZB) {  // this block's channels
+        in += zb * CONV_DP;
+        out += zb * CONV_DP;
+        if (RESID) data += zb * CONV_DP;
+    }
 
     if (wave == NW) {
         // ---- loader wavefront: input rows travel in pairs ---------------------------
@@ -292,7 +316,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
         auto lane_col = [&](int c) { return xs + (c * CONV_DP + 2 * lane) / DP; };
         for (int c = 0; c < NCH; ++c) {
             const int xx = lane_col(c);
-            if (xx < 0 || xx >= A.W)
+            if (xx < 0 || xx >= A.W || !zok)
                 for (int b = 0; b < NBUF; ++b)
                     *reinterpret_cast<double2 *>(rows + (size_t)b * RBUF + (size_t)c * CONV_DP + 2 * lane) =
                         make_double2(0.0, 0.0);
@@ -307,14 +331,16 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
                         make_double2(0.0, 0.0);
                 return;
             }
-            const double *src = in + (long)r * rowstride + (long)xs * DP + 2 * lane;
+            const double *src = in + (long)r * rowstride + (long)xs * cstride + 2 * lane;
 #if defined(D3D_CONV_DIAG) && D3D_CONV_DIAG == 1
             return;  // diagnostic: no loads at all (compute floor)
 #endif
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int xx = lane_col(c);
-                if (xx >= 0 && xx < A.W) conv_glds16(src + (long)c * CONV_DP, dst + (size_t)c * CONV_DP);
+                // (ZB: chunk c is column xs + c, cstride doubles further on)
+                if (xx >= 0 && xx < A.W && zok)
+                    conv_glds16(src + (long)c * (ZB ? cstride : CONV_DP), dst + (size_t)c * CONV_DP);
             }
         };
         __builtin_amdgcn_s_setprio(3);  // the loads are on everybody's critical path (-1 us)
@@ -332,7 +358,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
 
     // ---- compute wavefront: output columns x0 + wave SPW + (lane group) -------------------
     const int x = x0 + wave * SPW + lane / HLS;
-    const bool xok = x < A.W;
+    const bool xok = x < A.W && zok;
     if (x0 + wave * SPW >= A.W) {  // columns past the cube's edge: only keep the barriers company
         asm volatile("s_barrier" ::: "memory");
         for (int j = 0; j < npairs; ++j) asm volatile("s_barrier" ::: "memory");
@@ -370,8 +396,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_conv_rows(ConvRowsArgs A,
     asm volatile("s_barrier" ::: "memory");  // prologue
     // blocks of FS steps (the ring rotates through static registers)
     for (int base = 0; base < nsteps; base += FS)
-        conv_rows_steps<FS, NW, LSF, RESID, TSYM == 2, DPS>(base, nsteps, y0, yend, rowstride, x, xok, wave,
-                                                            lane, rows, myspec, q, w, data, out, ring, dnext);
+        conv_rows_steps<FS, NW, LSF, RESID, TSYM == 2, DPS, ZB>(base, nsteps, y0, yend, rowstride, cstride, x,
+                                                                xok, wave, lane, rows, myspec, q, w, data,
+                                                                out, ring, dnext);
 }
 
 }  // namespace d3d

@@ -210,6 +210,7 @@ struct d3d_ctx {
     bool fsf_symt = false;        // ... and fsf[k][i] == fsf[i][k] bit for bit (radial FSFs)
     bool lsf_dense_sym = false;   // dense LSF weights mirror-symmetric bit for bit
     int conv_rows = 1;            // D3D_CONV_ROWS=0: never use the one-pass kernel k_conv_rows
+    int conv_zb = 1;              // option conv_zb = 0: depths above 128 keep the march kernels (no z-blocks)
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave

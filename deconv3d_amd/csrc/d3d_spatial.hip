@@ -364,6 +364,10 @@ bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     if (c->Dp == 64 || c->Dp == 32)  // several spectra per wavefront: the BASELINE footprints,
         return (c->fw == 9 || c->fw == 11) &&
                (c->fsf_symt || (c->fsf_sep && c->march_mode > 0));  // radial or outer-product FSFs
+    // every other depth above 64: z-blocks of 128 channels (the last one ragged), FSF only --
+    // the LSF couples the blocks
+    if (c->Dp > 64 && c->Dp != d3d::CONV_DP)
+        return !with_lsf && c->conv_zb && (c->fw == 9 || c->fw == 11 || c->fw == 13);
     if (c->Dp != d3d::CONV_DP) return false;
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: return true;
@@ -371,30 +375,32 @@ bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     }
 }
 
-template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = d3d::CONV_DP>
+template <int FS, bool LSF, bool LSYM, bool RESID, int TSYM, int DPS = d3d::CONV_DP, bool ZB = false>
 int launch_conv_rows_t(d3d_ctx *c, const double *in, double *out, const double *data) {
     constexpr int NW = 15;
     constexpr int NWC = d3d::ConvGeo<FS, NW, DPS>::NWC;  // output columns per workgroup
     d3d::ConvRowsArgs A;
     A.H = c->H;
     A.W = c->W;
+    A.Dp = c->Dp;
     A.ngx = (c->W + NWC - 1) / NWC;
+    const int nzb = ZB ? (c->Dp + d3d::CONV_DP - 1) / d3d::CONV_DP : 1;  // z-blocks of 128 channels
     // one workgroup per CU (1024 threads, ~93 KB of LDS): as many row strips as fill the
     // chip in ONE round
     const int cus = c->flow_grid > 0 ? c->flow_grid / 4 : 256;
-    int ngy = std::max(1, cus / A.ngx);
+    int ngy = std::max(1, cus / (A.ngx * nzb));
     ngy = std::min(ngy, c->H);
     A.HY = (c->H + ngy - 1) / ngy;
     if (c->conv_hy_opt >= 1) A.HY = c->conv_hy_opt;
     A.ngy = (c->H + A.HY - 1) / A.HY;
     A.xcd_remap = 1;
-    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM, DPS>;
+    auto kern = d3d::k_conv_rows<FS, NW, LSF, LSYM, RESID, TSYM, DPS, ZB>;
     constexpr size_t lds = d3d::conv_rows_lds_bytes<FS, NW, DPS>();
     // > 64 KB of dynamic LDS has to be allowed per function AND per device: set on every
     // launch (a host-side call of a few microseconds; this kernel is not in the MH loop)
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy)), dim3((NW + 1) * 64), lds, c->stream, A,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(A.ngx * A.ngy * nzb)), dim3((NW + 1) * 64), lds, c->stream, A,
                        in, out, (const double *)(TSYM == 2 ? c->fsf_quad_sep : c->fsf_quad),
                        (const double *)c->lsf_dense, data);
     HIP_TRY(hipGetLastError());
@@ -419,7 +425,29 @@ int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double 
     return fail(D3D_ERR_STATE, "internal: no one-pass kernel for this FSF at %d channels", c->Dp);
 }
 
+// any depth above 128: z-blocks, FSF only
+template <int FS>
+int launch_conv_rows_zb(d3d_ctx *c, const double *in, double *out, const double *data) {
+    constexpr int DP = d3d::CONV_DP;
+    if (c->fsf_sep && c->march_mode > 0)
+        return data ? launch_conv_rows_t<FS, false, false, true, 2, DP, true>(c, in, out, data)
+                    : launch_conv_rows_t<FS, false, false, false, 2, DP, true>(c, in, out, data);
+    if (c->fsf_symt)
+        return data ? launch_conv_rows_t<FS, false, false, true, 1, DP, true>(c, in, out, data)
+                    : launch_conv_rows_t<FS, false, false, false, 1, DP, true>(c, in, out, data);
+    return data ? launch_conv_rows_t<FS, false, false, true, 0, DP, true>(c, in, out, data)
+                : launch_conv_rows_t<FS, false, false, false, 0, DP, true>(c, in, out, data);
+}
+
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
+    if (c->Dp > 64 && c->Dp != d3d::CONV_DP) {
+        if (lsf) return fail(D3D_ERR_STATE, "internal: one-pass LSF requested at %d channels", c->Dp);
+        switch (c->fw) {
+            case 9: return launch_conv_rows_zb<9>(c, in, out, data);
+            case 11: return launch_conv_rows_zb<11>(c, in, out, data);
+            default: return launch_conv_rows_zb<13>(c, in, out, data);
+        }
+    }
     if (c->Dp == 64)
         return c->fw == 9 ? launch_conv_rows_fs<9, 64>(c, in, out, data, lsf)
                           : launch_conv_rows_fs<11, 64>(c, in, out, data, lsf);

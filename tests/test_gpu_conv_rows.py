@@ -1,6 +1,7 @@
 """
 k_conv_rows (csrc/d3d_conv.h): the one-pass LSF (x) FSF convolution for 128-, 64- and
-32-channel cubes and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
+32-channel cubes (and, FSF only, in z-blocks of 128 channels for every depth above 128)
+and mirror-symmetric FSFs -- loader wavefront + LDS row ring + one-column
 register rings + LSF epilogue -- against the oracle's restatement of
 lib/convolution.py:89-120 and lib/run.py:1027-1029, and against the two-pass
 kernels it replaces (option conv_rows = 0).  Shapes chosen to hit every border case of
@@ -51,6 +52,13 @@ CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
     (32, 21, 63, 11, "asym", 5),          # 60 columns per workgroup + 3
     (32, 7, 2, 9, "muse", None),
     (63, 14, 22, 11, "muse", None),       # padded depth 64: FSF pass only
+    # above 128 channels: the FSF pass in z-blocks of 128 channels (LSF in a pass of its own)
+    (256, 23, 19, 11, "muse", None),      # two full blocks
+    (200, 17, 31, 9, "asym", 5),          # ragged last block (72 channels), 2 workgroups + 1 column
+    (130, 12, 16, 13, "none", None),      # last block: ONE z-pair
+    (384, 9, 33, 11, "muse", 4),          # three blocks
+    (301, 6, 7, 9, "muse", None),         # odd depth: padded to 302
+    (1500, 5, 6, 11, "muse", None),       # a deep cube (thread-looped line / LSF kernels): 12 blocks
 ]
 
 
@@ -74,7 +82,8 @@ def test_one_pass_convolution_matches_the_oracle_and_the_two_pass_kernels(D, H, 
 
 
 @pytest.mark.parametrize("D,H,W,fs,hy", [(128, 21, 34, 11, 8), (128, 17, 16, 9, None),
-                                         (64, 21, 34, 11, 8), (32, 17, 16, 9, None)])
+                                         (64, 21, 34, 11, 8), (32, 17, 16, 9, None),
+                                         (256, 21, 34, 11, 8), (200, 17, 16, 9, None)])
 def test_forward_model_and_residual_through_the_one_pass_kernel(D, H, W, fs, hy):
     """params -> lines -> FSF, plain and with the data - sim epilogue
     (lib/run.py:999-1031), with masked spaxels."""
@@ -97,7 +106,7 @@ def test_forward_model_and_residual_through_the_one_pass_kernel(D, H, W, fs, hy)
     assert np.max(np.abs(err - (data - want))) <= 1e-12 * np.max(np.abs(data - want))
 
 
-@pytest.mark.parametrize("D", [128, 64, 32])
+@pytest.mark.parametrize("D", [128, 64, 32, 256, 200])
 def test_one_pass_kernel_is_position_independent(D):
     """The march always runs top-down: a cube cut out of a larger one (with the FSF
     half width of context) gives the very same bits on the common interior -- which is
@@ -118,3 +127,32 @@ def test_one_pass_kernel_is_position_independent(D):
         part = eng.download_slot(_lib.SLOT_SIM)
     h = fs // 2
     np.testing.assert_array_equal(part[:, h:-h, h:-h], full[:, y0 + h:y1 - h, x0 + h:x1 - h])
+
+
+@pytest.mark.parametrize("kind", ["radial", "elliptical", "outer product"])
+@pytest.mark.parametrize("D", [256, 168])
+def test_z_blocked_fsf_pass_for_every_symmetric_fsf_class(kind, D):
+    """Depths above 128 (option conv_zb): each of the kernel's three tap forms -- radial
+    (transposition-symmetric quadrant), mirror-symmetric only (an elliptical Gaussian with
+    pa = 0, lib/spread_functions.py:113-131), outer product (a circular Gaussian) -- against
+    scipy's convolve2d per channel (the oracle's spatial pass) and the march kernels
+    (conv_zb = 0)."""
+    rng = np.random.default_rng(3)
+    H, W = 19, 33
+    fsf = {"radial": O.moffat_cropped(11, 3.0, 2.5),
+           "elliptical": O.gaussian_fsf_image(4.2, pa=0., ba=0.6),
+           "outer product": O.gaussian_fsf_image(4.2)}[kind]
+    assert fsf.shape[0] in (9, 11, 13)
+    cube = rng.normal(size=(D, H, W))
+    want = O.spatial_convolve(cube, fsf)
+    outs = []
+    for zb in (1, 0):
+        with _lib.Engine((D, H, W), fsf.shape, options={"conv_zb": zb, "conv_hy": 7}) as eng:
+            eng.set_taps(fsf, None)
+            eng.upload_slot(_lib.SLOT_TMP0, cube)
+            eng.convolve_slots(_lib.SLOT_TMP0, _lib.SLOT_SIM)
+            outs.append(eng.download_slot(_lib.SLOT_SIM))
+    scale = np.max(np.abs(want))
+    for got in outs:
+        assert np.max(np.abs(got - want)) <= 1e-12 * scale
+    assert not np.array_equal(outs[0], outs[1])        # two kernels did run
