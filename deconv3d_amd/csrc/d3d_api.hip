@@ -417,6 +417,7 @@ const OptDesc g_opts[] = {
     {"zmajor", "D3D_ZMAJOR", &d3d_ctx::zmajor, OPT_LAUNCH, 0, 1},
     {"zmajor_hy", "D3D_ZMAJOR_HY", &d3d_ctx::zmajor_hy, OPT_LAUNCH, 1, 1 << 20},
     {"spectral_dense", "D3D_SPECTRAL_DENSE", &d3d_ctx::spectral_dense, OPT_LAUNCH, 0, 1},
+    {"spectral_blocks", "D3D_SPECTRAL_BLOCKS", &d3d_ctx::spectral_blocks, OPT_LAUNCH, 0, 1},
     {"spatial_nt", "D3D_SPATIAL_NT", &d3d_ctx::sp_nt_opt, OPT_LAUNCH, 0, 1024},
     {"xcd_remap", "D3D_XCD_REMAP", &d3d_ctx::xcd_remap, OPT_LAUNCH, 0, 1},
     {"alt_dir", "D3D_ALT_DIR", &d3d_ctx::alt_dir, OPT_LAUNCH, 0, 1},
@@ -833,6 +834,22 @@ static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, doubl
     // dense form for the fused epilogue: out[k] = sum_j wl[j] v[(k + j - RL) mod N]
     c->lsf_fusable = false;
     c->lsf_dense_ok = false;
+    c->lsf_dense_any = false;
+    if (c->ntaps) {  // any depth: taps within +-LSF_RL channels (k_spectral_blocks)
+        std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
+        bool ok = c->N >= 4 * d3d::LSF_RL;
+        for (size_t t = 0; ok && t < shift.size(); ++t) {
+            const int sg = shift[t] > c->N / 2 ? shift[t] - c->N : shift[t];
+            if (sg < -d3d::LSF_RL || sg > d3d::LSF_RL) ok = false;
+            else dense[sg + d3d::LSF_RL] += weight[t];
+        }
+        if (ok) {
+            HIP_TRY(hipMemcpyAsync(c->lsf_dense, dense.data(), dense.size() * sizeof(double),
+                                   hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->lsf_dense_any = true;
+        }
+    }
     if (c->ntaps && c->N == c->D && c->D >= 4 * d3d::LSF_RL) {
         std::vector<double> dense(2 * d3d::LSF_RL + 1, 0.0);
         bool ok = true;

@@ -213,6 +213,8 @@ struct d3d_ctx {
     int conv_zb = 1;              // option conv_zb = 0: depths above 128 keep the march kernels (no z-blocks)
     double *lsf_dense = nullptr;  // [2*LSF_RL+1] dense LSF weights for the fused epilogue
     bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
+    bool lsf_dense_any = false;   // taps within +-LSF_RL channels at ANY depth (k_spectral_blocks)
+    int spectral_blocks = 1;      // option spectral_blocks = 0: never use k_spectral_blocks
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
     int spectral_shfl = 0;        // D3D_SPECTRAL_SHFL=1: wavefront shuffles instead of the LDS window

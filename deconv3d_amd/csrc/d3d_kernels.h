@@ -237,6 +237,65 @@ __global__ __launch_bounds__(NT) void k_spectral_dense(int Dp, int HL, long nspa
     *reinterpret_cast<double2 *>(out + sp * Dp + 2 * zl) = acc;
 }
 
+// The dense form for ANY depth (round 3): a wavefront takes one 128-channel BLOCK of one
+// spectrum, [z0, z0 + 128), and the LSF_RL channels either side of it,
+//   out[k] = sum_j wl[j] * ext[(k + j - LSF_RL) mod N],  ext = the spectrum zero-extended to N
+// (closed form of convolve_1d for every depth: lib/convolution.py:89-160 -- the wrap of the
+// power-of-two padded grid, including the partial wrap of depths within LSF_RL of N, is the
+// "mod N, zero beyond D" of the halo loads).  Wave-private LDS window, no block barrier, no
+// limit on the depth: streaming, HBM-bound.  The halo channels are read a second time (from
+// L2: the neighbouring block's wavefront reads them too): 144 channels per 128.
+static __global__ __launch_bounds__(256) void k_spectral_blocks(int D, int Dp, int N, int nzb, long nwaves,
+                                                                const double *__restrict__ wl,
+                                                                const double *__restrict__ in,
+                                                                double *__restrict__ out) {
+    __shared__ double smem[4 * (128 + 2 * LSF_RL)];
+    constexpr int RL = LSF_RL;
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= nwaves) return;
+    const long sp = wv / nzb;
+    const int z0 = (int)(wv - sp * nzb) * 128;
+    const double *src = in + sp * Dp;
+    double *buf = smem + (size_t)(threadIdx.x >> 6) * (128 + 2 * RL);
+    // value pair at (even) position m of the zero-extended, N-periodic spectrum
+    auto fetch = [&](int m) {
+        int idx = m % N;
+        if (idx < 0) idx += N;
+        double2 v = make_double2(0.0, 0.0);
+        if (idx < D) {  // (idx even, Dp even: idx + 1 < Dp; the padding channel holds zero)
+            v = *reinterpret_cast<const double2 *>(src + idx);
+            if (idx + 1 >= D) v.y = 0.0;
+        }
+        return v;
+    };
+    *reinterpret_cast<double2 *>(buf + RL + 2 * lane) = fetch(z0 + 2 * lane);
+    if (lane < RL / 2) *reinterpret_cast<double2 *>(buf + 2 * lane) = fetch(z0 - RL + 2 * lane);
+    else if (lane < RL) *reinterpret_cast<double2 *>(buf + 128 + RL + 2 * (lane - RL / 2)) =
+        fetch(z0 + 128 + 2 * (lane - RL / 2));
+    __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS is in order per wave
+    double w[2 * RL + 2];
+#pragma unroll
+    for (int j = 0; j < RL + 1; ++j) {
+        const double2 p = *reinterpret_cast<const double2 *>(buf + 2 * lane + 2 * j);
+        w[2 * j] = p.x;
+        w[2 * j + 1] = p.y;
+    }
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < 2 * RL + 1; ++j) {
+        const double t = wl[j];
+        acc.x = fma(t, w[j], acc.x);
+        acc.y = fma(t, w[j + 1], acc.y);
+    }
+    const int z = z0 + 2 * lane;
+    if (z < Dp) {
+        if (z >= D) acc.x = 0.0;  // the padding channel of an odd depth stays zero
+        if (z + 1 >= D) acc.y = 0.0;
+        *reinterpret_cast<double2 *>(out + sp * Dp + z) = acc;
+    }
+}
+
 // The same pass with wavefront shuffles instead of the LDS window (HL == 64: one
 // spectrum per wavefront, so the circular wrap is the wrap of the lane index):
 // lane l needs channels 2l-8 .. 2l+9, i.e. both components of lanes l-4 .. l+4,

@@ -71,6 +71,17 @@ int launch_spectral_nt(d3d_ctx *c, const double *in, double *out) {
 }
 
 int launch_spectral(d3d_ctx *c, const double *in, double *out) {
+    // taps within +-8 channels, any depth that is not served by the one-wavefront dense form:
+    // 128-channel blocks, one wavefront each (streaming)
+    if (c->lsf_dense_any && c->spectral_blocks && !(c->lsf_fusable && c->spectral_dense)) {
+        const int nzb = (c->Dp + 127) / 128;
+        const long nwaves = (long)c->HW * nzb;
+        hipLaunchKernelGGL(d3d::k_spectral_blocks, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0,
+                           c->stream, c->D, c->Dp, c->N, nzb, nwaves, (const double *)c->lsf_dense, in,
+                           out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (c->deep) {
         d3d::SpectralArgs A = spectral_args(c);
         const size_t lds = (size_t)c->N * sizeof(double);

@@ -59,6 +59,12 @@ CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
     (384, 9, 33, 11, "muse", 4),          # three blocks
     (301, 6, 7, 9, "muse", None),         # odd depth: padded to 302
     (1500, 5, 6, 11, "muse", None),       # a deep cube (thread-looped line / LSF kernels): 12 blocks
+    # the LSF pass in 128-channel blocks (k_spectral_blocks): depths within 8 channels of the
+    # power-of-two padded length wrap partially (lib/convolution.py:137-160)
+    (255, 6, 5, 9, "asym", None),
+    (249, 4, 9, 11, "asym", None),
+    (1020, 3, 4, 9, "asym", None),
+    (100, 7, 6, 9, "asym", None),         # one ragged block
 ]
 
 
