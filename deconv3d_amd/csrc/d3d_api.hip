@@ -136,7 +136,7 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (c->mh_layers_cfg < 1) c->mh_layers_cfg = 1;
     if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
     if (c->Dp > 160 && c->mh_layers_cfg > 2) c->mh_layers_cfg = 2;
-    if (c->mh_defer != 1 || c->mh_flow || c->Dp > 256) c->mh_layers_cfg = 1;
+    if (c->mh_defer != 1 || c->mh_flow || c->Dp > d3d::MH_WS_MAX_DP) c->mh_layers_cfg = 1;
     if (c->deep) c->mh_defer = 0;  // k_mh_deep writes the residual back at once
     c->mh_layers = c->mh_layers_cfg;
 }
@@ -1246,7 +1246,8 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     // deferred write-back with pending layers: the wave-specialised kernel (D <= 256);
     // an unpartitioned context may also use the plain deferred kernel
     const bool partitioned = c->tiled || c->parts.size() > 1;
-    const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
+    const bool deferred =
+        c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= d3d::MH_WS_MAX_DP));
     if (c->lay_n && (c->pend_part != pi || !deferred))
         if (int rc = flush_pending(c)) return rc;
 #ifdef D3D_EXPERIMENTS
@@ -1548,7 +1549,8 @@ int d3d_mh_layers(d3d_ctx *c, int *out) {
     NEED(c && out, D3D_ERR_INVALID, "NULL argument");
     NEED(c->have_data, D3D_ERR_STATE, "data not set");
     const bool partitioned = c->tiled || c->parts.size() > 1;
-    const bool deferred = c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= 256));
+    const bool deferred =
+        c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= d3d::MH_WS_MAX_DP));
     *out = deferred ? c->mh_layers : 0;
     return D3D_OK;
 }

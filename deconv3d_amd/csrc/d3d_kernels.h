@@ -1652,6 +1652,7 @@ struct MHArgs {
 #endif
 
 constexpr int MH_LAYERS = 3;  // pending colours k_mh_ws can apply in one pass
+constexpr int MH_WS_MAX_DP = 512;  // deepest cube k_mh_ws takes (512 streaming threads, thread <-> channel)
 
 // Staggered completion (MHArgs::prio; measured flat): 1..15 -- the
 // workgroups with bit prio-1 of their index set run at raised wave priority; 16 + n -- the

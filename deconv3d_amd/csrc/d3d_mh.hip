@@ -158,29 +158,29 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
 template <bool UV, int U, int M, int K, bool NTV = false, int NS = 256>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
+    hipError_t attr = hipSuccess;
+    auto go = [&](auto kern) {
+        // (more than 64 KB of dynamic LDS -- 512 channels with two pending layers -- has to be
+        // allowed per function)
+        if (lds > 65536)
+            attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NS + 64), lds, c->stream, P, sweep);
+    };
     // (the number of pending layers as a template constant: see k_mh_ws)
     switch (P.n_lay <= M ? P.n_lay : -1) {
-        case 0:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 0, NTV>), dim3(grid),
-                               dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
-        case 1:
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 1, NTV>), dim3(grid),
-                               dim3(NS + 64), lds, c->stream, P, sweep);
-            break;
+        case 0: go(d3d::k_mh_ws<NS, UV, U, M, K, 0, NTV>); break;
+        case 1: go(d3d::k_mh_ws<NS, UV, U, M, K, 1, NTV>); break;
         case 2:
-            if constexpr (M >= 2)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 2, NTV>), dim3(grid),
-                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            if constexpr (M >= 2) go(d3d::k_mh_ws<NS, UV, U, M, K, 2, NTV>);
             break;
         case 3:
-            if constexpr (M >= 3)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_ws<NS, UV, U, M, K, 3, NTV>), dim3(grid),
-                                   dim3(NS + 64), lds, c->stream, P, sweep);
+            if constexpr (M >= 3) go(d3d::k_mh_ws<NS, UV, U, M, K, 3, NTV>);
             break;
         default:
             return fail(D3D_ERR_STATE, "internal: %d pending layers for a %d-layer kernel", P.n_lay, M);
     }
+    HIP_TRY(attr);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -199,6 +199,26 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // (the uniform-variance variant also gains from the deeper queue at full size:
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
+    // 257 .. 512 channels (round 3): the same kernel with 512 streaming threads (thread <->
+    // channel in the tail; the staged G rows, 4 Dp <= 4 x 576, in four registers); the position
+    // groups (512 / HL) are those of k_mh_defer<512>, so the chain stays bit-identical to it
+    if (c->Dp > 256) {
+        bool ntv = false;
+        if constexpr (!UV) ntv = c->mh_nt_ivar && !(grid < (unsigned)c->flow_grid / 2);
+        const bool few = grid < (unsigned)c->flow_grid / 2;
+        if (layers >= 2) {
+            if (few) return launch_mh_ws_um<UV, 4, 2, 4, false, 512>(c, P, grid, sweep);
+            // (four positions in flight: 300x300x320 106 us per launch against 111 with two and 141
+            // with one; 300x300x512 186 / 187 / 225 -- two workgroups per CU, two rounds)
+            if constexpr (!UV)
+                if (ntv) return launch_mh_ws_um<UV, 4, 2, 4, true, 512>(c, P, grid, sweep);
+            return launch_mh_ws_um<UV, 4, 2, 4, false, 512>(c, P, grid, sweep);
+        }
+        if (few) return launch_mh_ws_um<UV, 4, 1, 4, false, 512>(c, P, grid, sweep);
+        if constexpr (!UV)
+            if (ntv) return launch_mh_ws_um<UV, 1, 1, 4, true, 512>(c, P, grid, sweep);
+        return launch_mh_ws_um<UV, 1, 1, 4, false, 512>(c, P, grid, sweep);
+    }
     // (with several layers most launches only read: two positions in flight pay at
     // full size, 43.3 -> 42.6 us per colour; chosen per kind of launch instead -- four for
     // the read-only launches, or one for the storing ones -- measures 45.3 / 41.3 us
@@ -354,9 +374,9 @@ int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
 
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
                     bool wide) {
-    // wave-specialised kernel: 256 streaming threads (thread <-> channel in the
-    // tail, so D <= 256) + one prepare wavefront
-    if (c->mh_defer == 1 && c->Dp <= 256) {
+    // wave-specialised kernel: 256 (or, above 256 channels, 512) streaming threads -- thread
+    // <-> channel in the tail, so D <= 512 -- + one prepare wavefront
+    if (c->mh_defer == 1 && c->Dp <= d3d::MH_WS_MAX_DP) {
         if (c->ivar_is_uniform && c->uniform_fast_path)
             return launch_mh_ws<true>(c, P, grid, sweep, layers, wide);
         return launch_mh_ws<false>(c, P, grid, sweep, layers, wide);

@@ -28,10 +28,10 @@ def small_problem(D, H, W, fsf, lsf, seed=0):
     return data, var, mask, truth, init, min_b, max_b
 
 
-@pytest.mark.parametrize("D", [100, 128, 200, 256, 300, 512, 1000, 1024, 1025, 2048, 3700])
+@pytest.mark.parametrize("D", [100, 128, 200, 256, 257, 300, 512, 513, 1000, 1024, 1025, 2048, 3700])
 def test_deep_cubes_chain_matches_oracle(D):
-    """Depths that select every MH kernel: wave-specialised (D <= 256), plain
-    deferred (D > 256), 256/512/1024-thread blocks, the z-blocked forms beyond 1024
+    """Depths that select every MH kernel: wave-specialised with 256 (D <= 256) or 512
+    streaming threads (D <= 512), plain deferred beyond, 256/512/1024-thread blocks, the z-blocked forms beyond 1024
     channels (a full MUSE cube has ~3700; lib/convolution.py:137-141 takes any depth),
     and non-power-of-two depths with the partial-wrap LSF."""
     H, W = 5, 6
@@ -54,6 +54,31 @@ def test_deep_cubes_chain_matches_oracle(D):
         np.testing.assert_allclose(eng.get_params(), st.params, rtol=1e-9, atol=1e-9)
         err = eng.download_slot(_lib.SLOT_ERR)
         assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
+
+
+@pytest.mark.parametrize("D", [300, 512])
+def test_512_thread_wave_specialised_kernel_is_bit_identical_to_the_other_schemes(D):
+    """257 .. 512 channels: k_mh_ws with 512 streaming threads -- one or two pending layers,
+    the few-windows form (four positions in flight) as chosen for this small cube -- against
+    the plain deferred kernel and the immediate one (same position groups: same bits)."""
+    H, W = 9, 13
+    fsf = O.gaussian_fsf_image(1.6)
+    lsf = O.gaussian_lsf_vector(D, 1.1)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=D + 1)
+    outs = []
+    for opts in ({"mh_defer": 1}, {"mh_defer": 1, "mh_layers": 2}, {"mh_defer": 2}, {"mh_defer": 0}):
+        with _lib.Engine((D, H, W), fsf.shape, options=opts) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.set_data(data, var, mask=mask)
+            eng.set_params(init)
+            eng.mh_config(min_b, max_b, 0.1, 40.0, seed=3, refresh_every=0)
+            if opts == {"mh_defer": 1, "mh_layers": 2}:
+                assert eng.mh_layers() == 2
+            acc = eng.mh_sweeps(3, 1)
+            outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), np.int64(acc)))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            np.testing.assert_array_equal(a, b)
 
 
 def test_depth_limit_is_reported():
@@ -207,7 +232,7 @@ def test_refresh_cadence_inside_mh_sweeps():
 def test_pending_layer_policy():
     """d3d_mh_layers: small cubes (colour launches that do not fill the chip) write
     the residual back every colour, option mh_layers forces a depth, depths beyond
-    160 / 256 channels cap it at 2 / 1, tiled contexts write at once."""
+    160 / 512 channels cap it at 2 / 1, tiled contexts write at once."""
     fsf = O.gaussian_fsf_image(1.6)
 
     def layers(D, forced=None):
@@ -224,5 +249,6 @@ def test_pending_layer_policy():
     assert layers(64, 2) == 2
     assert layers(64, 3) == 3
     assert layers(200, 3) == 2
-    assert layers(300, 3) == 1
+    assert layers(300, 3) == 2          # 512 streaming threads (257 .. 512 channels)
+    assert layers(600, 3) == 1          # beyond: the plain deferred kernel, one layer
 
