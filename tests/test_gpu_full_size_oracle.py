@@ -11,7 +11,9 @@ those shapes are compared with the CPU restatement itself, not only with each ot
   * a chip-filling cube with the beyond-the-Infinity-Cache policy forced on
     (non-temporal 1/variance loads, write-through residual stores) against the
     default policy, bit for bit, and against the oracle;
-  * the zig-zag walk switched off.
+  * the zig-zag walk switched off;
+  * a 264-channel cube whose launches fill the chip: the 512-thread form of k_mh_ws, both
+    cache policies.
 
 The oracle is fed the DEVICE's initial residual (the forward model has its own tests),
 so a 90 000-update sweep costs about 20 s of numpy on the GPU box's host.
@@ -126,6 +128,29 @@ def test_beyond_cache_policy_is_bit_identical_and_matches_the_oracle():
                 st = oracle_state(pb, err0)
                 for s in (1, 2):
                     O.mh_sweep(st, s)
+                assert_matches_oracle(eng, st, accepted, pb)
+            outs.append((eng.get_params(), eng.get_dlog(), eng.download_slot(_lib.SLOT_ERR),
+                         np.int64(accepted)))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_512_thread_kernel_with_chip_filling_launches_matches_the_oracle():
+    """257 .. 512 channels: k_mh_ws with 512 streaming threads, two pending layers, four
+    positions in flight -- the variants of launches that fill the chip (>= 512 windows per
+    colour class), with the default cache policy and with the beyond-cache one forced on
+    (non-temporal 1/variance, write-through residual): bit-identical to each other, and one
+    whole sweep equal to the oracle."""
+    outs = []
+    for nt in (0, 1):
+        eng, pb = build(264, 253, 253, 11, options={"mh_nt_ivar": nt})
+        with eng:
+            assert eng.mh_layers() == 2
+            err0 = start(eng, pb)
+            accepted = eng.mh_sweeps(1, 1)
+            if nt:
+                st = oracle_state(pb, err0)
+                O.mh_sweep(st, 1)
                 assert_matches_oracle(eng, st, accepted, pb)
             outs.append((eng.get_params(), eng.get_dlog(), eng.download_slot(_lib.SLOT_ERR),
                          np.int64(accepted)))
