@@ -136,8 +136,13 @@ void pick_mh_geometry(d3d_ctx *c) {
     if (c->mh_layers_cfg < 1) c->mh_layers_cfg = 1;
     if (c->mh_layers_cfg > d3d::MH_LAYERS) c->mh_layers_cfg = d3d::MH_LAYERS;
     if (c->Dp > 160 && c->mh_layers_cfg > 2) c->mh_layers_cfg = 2;
-    if (c->mh_defer != 1 || c->mh_flow || c->Dp > d3d::MH_WS_MAX_DP) c->mh_layers_cfg = 1;
-    if (c->deep) c->mh_defer = 0;  // k_mh_deep writes the residual back at once
+    // cubes deeper than k_mh_ws takes: its z-blocked form, when the LSF taps lie within +-8
+    // channels (every Gaussian / MUSE-like LSF; unknown before d3d_set_taps: assumed)
+    c->mh_defer = c->mh_defer_opt;
+    c->mh_zb = c->mh_zblocks && c->Dp > d3d::MH_WS_MAX_DP && c->mh_defer == 1 && !c->mh_flow &&
+               (!c->have_taps || c->ntaps == 0 || c->lsf_dense_any);
+    if (c->mh_defer != 1 || c->mh_flow || (c->Dp > d3d::MH_WS_MAX_DP && !c->mh_zb)) c->mh_layers_cfg = 1;
+    if (c->deep && !c->mh_zb) c->mh_defer = 0;  // k_mh_deep writes the residual back at once
     c->mh_layers = c->mh_layers_cfg;
 }
 
@@ -398,7 +403,8 @@ struct OptDesc {
     int lo, hi;
 };
 const OptDesc g_opts[] = {
-    {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer, OPT_MH, 0, 2},
+    {"mh_defer", "D3D_MH_DEFER", &d3d_ctx::mh_defer_opt, OPT_MH, 0, 2},
+    {"mh_zblocks", "D3D_MH_ZBLOCKS", &d3d_ctx::mh_zblocks, OPT_MH, 0, 1},
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
     {"mh_props", "D3D_MH_PROPS", &d3d_ctx::mh_props, OPT_LAUNCH, 0, 1},
@@ -624,7 +630,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->pair_state, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep,
-                    c->chain_cols, c->chain_flags, c->chain_G, c->props};
+                    c->chain_cols, c->chain_flags, c->chain_G, c->props, c->z_part, c->z_E};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -883,6 +889,11 @@ static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, doubl
     c->have_taps = true;
     c->err_valid = false;
     pend_clear(c);
+    if (c->Dp > d3d::MH_WS_MAX_DP) {  // the taps decide whether the z-blocked sweep kernels run
+        const bool was = c->mh_zb;
+        pick_mh_geometry(c);
+        if (c->mh_zb != was && c->have_data) return build_colour_lists(c);
+    }
     return D3D_OK;
 }
 
@@ -1247,7 +1258,8 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     // an unpartitioned context may also use the plain deferred kernel
     const bool partitioned = c->tiled || c->parts.size() > 1;
     const bool deferred =
-        c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= d3d::MH_WS_MAX_DP));
+        c->mh_defer &&
+        (!partitioned || (c->mh_defer == 1 && (c->Dp <= d3d::MH_WS_MAX_DP || c->mh_zb)));
     if (c->lay_n && (c->pend_part != pi || !deferred))
         if (int rc = flush_pending(c)) return rc;
 #ifdef D3D_EXPERIMENTS
@@ -1279,7 +1291,7 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         (void)pairs;
 #endif
         // small colour launches: the sweep's proposals come from one launch before them
-        const bool use_props = c->mh_props && pt.layers == 1 && !c->deep && deferred;
+        const bool use_props = c->mh_props && pt.layers == 1 && !c->deep && !c->mh_zb && deferred;
         if (use_props)
             if (int rc = ensure_proposals(c, sweep)) return rc;
         d3d::MHArgs P;
@@ -1298,7 +1310,8 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
             // the launch that finds `layers` layers pending applies them for good
             P.write_back = (c->lay_n >= pt.layers) ? 1 : 0;
             const int g_cur = pend_free_buf(c);
-            int rc = launch_mh_defer(c, P, (unsigned)n_all, sweep, pt.layers, pt.wide);
+            int rc = c->mh_zb ? launch_mh_zb(c, P, (unsigned)n_all, sweep, pt.layers)
+                              : launch_mh_defer(c, P, (unsigned)n_all, sweep, pt.layers, pt.wide);
             if (rc) return rc;
             if (P.write_back) c->lay_n = 0;
             // this launch's updates are the newest pending layer (local residues)
@@ -1550,7 +1563,8 @@ int d3d_mh_layers(d3d_ctx *c, int *out) {
     NEED(c->have_data, D3D_ERR_STATE, "data not set");
     const bool partitioned = c->tiled || c->parts.size() > 1;
     const bool deferred =
-        c->mh_defer && (!partitioned || (c->mh_defer == 1 && c->Dp <= d3d::MH_WS_MAX_DP));
+        c->mh_defer &&
+        (!partitioned || (c->mh_defer == 1 && (c->Dp <= d3d::MH_WS_MAX_DP || c->mh_zb)));
     *out = deferred ? c->mh_layers : 0;
     return D3D_OK;
 }

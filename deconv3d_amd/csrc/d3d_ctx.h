@@ -136,7 +136,14 @@ struct d3d_ctx {
 
     int mh_nt = 0, mh_maxit = 0;  // MH kernel geometry (derived: apply_mh_options)
     int mh_nt_opt = 0, mh_maxit_opt = -1;  // options mh_nt / mh_maxit (0 / -1: chosen per shape)
-    int mh_defer = 1;             // deferred residual write-back (k_mh_defer)
+    int mh_defer = 1;             // deferred residual write-back in effect (pick_mh_geometry: mh_defer_opt,
+                                  // 0 for deep cubes that cannot take the z-blocked kernels)
+    int mh_defer_opt = 1;         // option mh_defer
+    int mh_zblocks = 1;           // option mh_zblocks = 0: cubes deeper than 512 channels keep k_mh_defer / k_mh_deep
+    bool mh_zb = false;           // the z-blocked kernels run (k_mh_ws<..., ZBK> + k_mh_zdecide)
+    double *z_part = nullptr;     // [items of a launch][blocks][4 waves][8] wave sums
+    double *z_E = nullptr;        // [2][slots][Dp] lines of the updates of the last colour class
+    size_t z_part_cap = 0;        // doubles allocated
 #ifdef D3D_EXPERIMENTS
     unsigned long long *stampbuf = nullptr;  // D3D_MH_STAMP=1: [launch][workgroup][8]
     size_t stamp_launches = 0, stamp_next = 0, stamp_stride = 0;
@@ -264,6 +271,7 @@ int pend_free_buf(const d3d_ctx *c);
 void pend_push(d3d_ctx *c, int cy, int cx, int g);
 void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P);
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep);
+int launch_mh_zb(d3d_ctx *c, d3d::MHArgs &P, unsigned n_items, uint32_t sweep, int layers);
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
                     bool wide);
 int flush_pending(d3d_ctx *c);

@@ -1630,6 +1630,13 @@ struct MHArgs {
     // only (lib/run.py:369-388), so the three tan, the log and the two Philox blocks need
     // not sit on the critical path of a small colour launch (its prepare wavefront).
     const MHProposal *props;
+    // Z-blocked sweeps of deep cubes (k_mh_ws<..., ZBK>, k_mh_zdecide): the spectrum is cut into
+    // blocks of z_db channels, one workgroup per (window, block); z_part takes the blocks' wave
+    // sums [item][block][wave][8], z_E the LSF-convolved unit lines of the update,
+    // [2][slots][Dp] (current, proposed), from which k_mh_zdecide forms the G row.
+    double *z_part;
+    double *z_E;
+    int z_nb, z_db, z_slots;
     // Staggered completion (EXPERIMENTS builds, option mh_prio; mh_stagger): half of a
     // colour's windows finish streaming before the other half, so that their decisions
     // overlap the others' streams (measured flat: DESIGN.md section 3).
@@ -2243,6 +2250,15 @@ __host__ __device__ inline size_t mh_ws_lds_doubles(int NS, int HL, int Dp, int 
 // been written back in turn, so the chain stays bit-identical -- and only the
 // launch that finds M layers pending stores the result and starts over.  One
 // residual write per M colours instead of one per colour.
+// Z-blocked form (ZBK): what a workgroup needs to know about its block beyond the argument
+// copy whose counts (D, Dp, HL, N) and pointers (err, ivar, G rows) describe the block alone.
+struct MHZ {
+    int z0;         // first channel of the block
+    int Nfull;      // padded length of the whole spectrum (power of two)
+    int Dfull;      // depth of the whole spectrum
+    long zs;        // doubles between two spaxels' spectra (the cube's Dp)
+};
+
 struct MHWsItem {
     int y, x, real;
     int n_lay, write_back;
@@ -2331,9 +2347,9 @@ struct MHGpRegs {
     double v[M][K_];
 };
 
-template <int M, int K, bool COH>
+template <int M, int K, bool COH, bool ZBK = false>
 __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I, int NT,
-                                              MHGpRegs<M, K> &R) {
+                                              MHGpRegs<M, K> &R, long zs = 0) {
     const int Dp = P.Dp;
     // (one scalar register for all K loads: left to itself the compiler re-fetches the kernel
     // argument in front of every one of them -- four dependent scalar loads in the setup of a
@@ -2353,7 +2369,7 @@ __device__ __forceinline__ void mh_ws_gp_load(const MHArgs &P, const MHWsItem &I
                 const int sx = (q & 1) ? px1 : px0;
                 if (sy >= 0 && sx >= 0) {
                     const double *src =
-                        I.lay_G[j] + ((long)(sy / P.fh) * slots_x + sx / P.fw) * Dp + z;
+                        I.lay_G[j] + ((long)(sy / P.fh) * slots_x + sx / P.fw) * (ZBK ? zs : (long)Dp) + z;
                     if (COH)
                         R.v[j][k] = __longlong_as_double((long long)__hip_atomic_load(
                             reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED,
@@ -2382,11 +2398,12 @@ __device__ __forceinline__ void mh_ws_gp_store(const MHArgs &P, const MHShared &
 // A virtual item that is a masked spaxel INSIDE the cube has no update: it leaves
 // a zero G row, so that the next colour can apply "every lattice point inside
 // the cube" without looking the mask up (one dependent load less in its setup).
-template <bool COH>
-__device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &I) {
+template <bool COH, bool ZBK = false>
+__device__ __forceinline__ void mh_ws_zero_row(const MHArgs &P, const MHWsItem &I, long zs = 0) {
     const int tid = threadIdx.x;
     if (tid < P.Dp && I.y >= 0 && I.y < P.H && I.x >= 0 && I.x < P.W) {
-        double *dst = I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * P.Dp + tid;
+        double *dst =
+            I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * (ZBK ? zs : (long)P.Dp) + tid;
         if (COH)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), 0ULL, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -2429,8 +2446,9 @@ struct MHPre {
 // The loads of the first window round of a streaming thread (positions g + u G), issued
 // before the workgroup's setup: S.pos is not built yet, so the voxel index is computed
 // here -- the same expression as mh_ws_table's.
-template <int NS, bool UV, int U, bool NTV = false>
-__device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &I, MHPre<U> &R) {
+template <int NS, bool UV, int U, bool NTV = false, bool ZBK = false>
+__device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &I, MHPre<U> &R,
+                                               long zs = 0) {
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp;
     const int G = NS / HL;
@@ -2453,19 +2471,48 @@ __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &
             const bool inside = yy >= P.dy0 && yy < P.dy1 && xx >= P.dx0 && xx < P.dx1;
             R.vox[u] = inside ? yy * P.W + xx : -1;
         }
-        const long idx = (long)max(R.vox[u], 0) * Dp + 2 * zl;
+        const long idx = (long)max(R.vox[u], 0) * (ZBK ? zs : (long)Dp) + 2 * zl;
         R.e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
         if (!UV) R.v[u] = mh_load_ivar<NTV>(P.ivar + idx);
     }
 }
 
+// ZBK: the LSF-convolved unit lines of one block.  L holds the zero-extended, Nfull-periodic
+// unit line on the block's channels and LSF_RL either side (L[i] <-> channel z0 - LSF_RL + i);
+// the taps (all within +-LSF_RL: the host checks) in the order mh_lsf takes them.
+__device__ __forceinline__ void mh_lsf_block(const MHArgs &P, const MHZ &Z, const double *LO,
+                                             const double *LN, int ch, double *EO, double *EN) {
+    double eo = 0.0, en = 0.0;
+    if (ch < P.D) {
+        if (P.ntaps > 0) {
+            for (int t = 0; t < P.ntaps; ++t) {
+                const int sh = P.shift[t];
+                const int j = ch + LSF_RL + (sh > Z.Nfull / 2 ? sh - Z.Nfull : sh);
+                const double wt = P.weight[t];
+                eo = fma(wt, LO[j], eo);
+                en = fma(wt, LN[j], en);
+            }
+        } else {
+            eo = LO[ch + LSF_RL];
+            en = LN[ch + LSF_RL];
+        }
+    }
+    *EO = eo;
+    *EN = en;
+}
+
 // PROPS: the launch may take its proposals from the sweep's table (MHArgs::props; the small
 // launches' variants only: the others keep the table out of their code).
+// ZBK: P describes ONE z-block of the window (counts and pointers; Z the rest); the run ends
+// with the block's wave sums and its lines handed to k_mh_zdecide (item = the window's index
+// in the launch).
 template <int NS, bool UV, bool COH, int U, int M, bool COHG = COH, bool PRE = false, bool NTV = false,
-          bool PROPS = false>
+          bool PROPS = false, bool ZBK = false>
 __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, const MHWsItem &I,
                                           uint32_t sweep, long stamp_at,
-                                          const MHPre<U> *pre = nullptr) {
+                                          const MHPre<U> *pre = nullptr, const MHZ *Zp = nullptr,
+                                          int item = 0, int zb = 0) {
+    const long zstride = ZBK ? Zp->zs : (long)P.Dp;  // doubles between two spaxels' spectra
     constexpr int ROW = 1 + M;
     const int tid = threadIdx.x;
     const int HL = P.HL, Dp = P.Dp, N = P.N;
@@ -2480,7 +2527,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     const bool streamer = tid < NS;
     // the uniforms of the Gibbs draw, while the first loads of the window pass fly
     U2 u_gibbs = {0.5, 0.5};
-    if (streamer && real && !P.ext_lines)
+    if (!ZBK && streamer && real && !P.ext_lines)
         u_gibbs = philox_pair(P.seed, (uint32_t)((I.y + P.gy0) * P.Wg + (I.x + P.gx0)), sweep,
                               BLK_GIBBS);
     if (streamer) {
@@ -2494,7 +2541,9 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             union { double2 d; v4u i; } cv;
             const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                P.err, 0, (COH || NTV) ? (int)((long)P.H * P.W * Dp * 8) : 0, 0x00020000);
+                P.err, 0,
+                (COH || NTV) ? (int)(((long)P.H * P.W * zstride - (ZBK ? Zp->z0 : 0)) * 8) : 0,
+                0x00020000);
             // U window positions per round: all their loads are issued before the
             // first is consumed.  U = 1 when a launch fills the chip (the stream is at
             // the HBM peak; more requests in flight only add contention: 52.9 vs
@@ -2511,7 +2560,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                     const int pw = p0 + u * G;
                     const int p = I.rev ? P.npos - 1 - pw : pw;
                     vox[u] = (pw < P.npos) ? S.pos[ROW * p] : -1;
-                    const long idx = (long)max(vox[u], 0) * Dp + 2 * zl;
+                    const long idx = (long)max(vox[u], 0) * zstride + 2 * zl;
                     if (COH) {
                         cv.i = __builtin_amdgcn_raw_buffer_load_b128(err_rsrc, (int)(idx * 8), 0, 16);
                         e[u] = cv.d;
@@ -2528,7 +2577,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                     if (vox[u] < 0) continue;
                     const int pw = p0 + u * G;
                     const int p = I.rev ? P.npos - 1 - pw : pw;
-                    const long idx = (long)vox[u] * Dp + 2 * zl;
+                    const long idx = (long)vox[u] * zstride + 2 * zl;
                     // the pending layers, oldest first: e <- e + f G of each
                     bool touched = false;
 #pragma unroll
@@ -2592,14 +2641,26 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     } else if (real) {
         const int lane = tid - NS;
         const MHProposal q = PROPS ? mh_proposal_of(P, sp, sweep) : mh_propose(P, sp, sweep);
-        for (int j = lane; j < N; j += 64) {
-            S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
-            S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+        if constexpr (ZBK) {
+            // the block's channels and LSF_RL either side of the zero-extended periodic line
+            // (N = block length + 2 LSF_RL here)
+            for (int j = lane; j < N; j += 64) {
+                int m = (Zp->z0 - LSF_RL + j) % Zp->Nfull;
+                if (m < 0) m += Zp->Nfull;
+                S.gO[j] = (m < Zp->Dfull) ? unit_gaussian((double)m, q.c_old, q.w_old) : 0.0;
+                S.gN[j] = (m < Zp->Dfull) ? unit_gaussian((double)m, q.pn[1], q.pn[2]) : 0.0;
+            }
+        } else {
+            for (int j = lane; j < N; j += 64) {
+                S.gO[j] = (j < P.D) ? unit_gaussian((double)j, q.c_old, q.w_old) : 0.0;
+                S.gN[j] = (j < P.D) ? unit_gaussian((double)j, q.pn[1], q.pn[2]) : 0.0;
+            }
         }
         __builtin_amdgcn_wave_barrier();  // wave-private region: LDS is in order per wave
         for (int ch = lane; ch < Dp; ch += 64) {
             double EO, EN;
-            mh_lsf(P, S.gO, S.gN, ch, &EO, &EN);
+            if constexpr (ZBK) mh_lsf_block(P, *Zp, S.gO, S.gN, ch, &EO, &EN);
+            else mh_lsf(P, S.gO, S.gN, ch, &EO, &EN);
             S.G[ch] = EO;
             sEN[ch] = EN;
         }
@@ -2608,7 +2669,7 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
     }
     D3D_MH_STAMP(stamp_at, 2, 0);
     if (!real) {
-        mh_ws_zero_row<COHG>(P, I);
+        mh_ws_zero_row<COHG, ZBK>(P, I, zstride);
         return;
     }
     __syncthreads();  // group partial sums are in S.red, the lines in S.G / sEN
@@ -2620,6 +2681,23 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             EO = S.G[tid];
             EN = sEN[tid];
         }
+    }
+    if constexpr (ZBK) {
+        // the block's share of the decision: its wave sums and its lines go to memory, the
+        // totals over the blocks are k_mh_zdecide's
+        if (streamer) {
+            mh_channel_sums(P, S, q, tid, G, EO, EN, 0);
+            if (tid < Dp) {
+                const long slot = (long)(I.y / P.fh) * P.slots_x + I.x / P.fw;
+                double *e0 = P.z_E + slot * zstride + Zp->z0 + tid;
+                e0[0] = EO;
+                e0[(long)P.z_slots * zstride] = EN;
+            }
+        }
+        __syncthreads();
+        constexpr int NWS = NS / 64;
+        if (tid < NWS * 8) P.z_part[((long)item * P.z_nb + zb) * (NWS * 8) + tid] = S.sum[tid];
+        return;
     }
     double Gt;
     if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs)) return;
@@ -2640,10 +2718,56 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 // As a compile-time constant the "layer j is live" tests of the setup fold away -- and with
 // them a store at a run-time index that kept the item's small arrays, and three dependent
 // scratch round trips, in every workgroup's setup.
-template <int NS, bool UV, int U, int M, int K, int NL = -1, bool NTV = false>
+// ZBK (round 3, cubes deeper than MH_WS_MAX_DP channels): grid = windows x z-blocks of z_db
+// channels; a workgroup runs the kernel on ITS block -- the arguments' counts and pointers are
+// rewritten to describe the block alone, only the spaxel stride stays the cube's -- up to the
+// wave sums of the decision, which k_mh_zdecide totals over the blocks.
+template <int NS, bool UV, int U, int M, int K, int NL = -1, bool NTV = false, bool ZBK = false>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
+    if constexpr (ZBK) {
+        const int item = blockIdx.x / P.z_nb, zb = blockIdx.x - item * P.z_nb;
+        MHZ Z;
+        Z.z0 = zb * P.z_db;
+        Z.Nfull = P.N;
+        Z.Dfull = P.D;
+        Z.zs = P.Dp;
+        const int db = min(P.z_db, P.Dp - Z.z0);  // (even: z_db and Dp are)
+        P.err += Z.z0;
+        P.ivar += Z.z0;
+        P.Gcur += Z.z0;
+#pragma unroll
+        for (int j = 0; j < MH_LAYERS; ++j) P.lay_G[j] += Z.z0;
+        P.D = max(0, min(db, Z.Dfull - Z.z0));
+        P.Dp = db;
+        P.HL = db / 2;
+        P.N = db + 2 * LSF_RL;
+        const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
+        const int4 ent = P.spx[item];
+        MHWsItem I;
+        I.y = ent.x;
+        I.x = ent.y;
+        I.real = ent.z;
+        mh_ws_layers_from_args(P, I);
+        if constexpr (NL >= 0) I.n_lay = NL;
+        if (!I.real && (I.n_lay == 0 || !I.write_back)) {
+            mh_ws_zero_row<false, true>(P, I, Z.zs);
+            return;
+        }
+        mh_ws_preds<M>(P, I);
+        MHGpRegs<M, K> gv;
+        mh_ws_gp_load<M, K, false, true>(P, I, NT, gv, Z.zs);
+        const double tap0 = ((int)threadIdx.x < P.npos) ? P.fsf[threadIdx.x] : 0.0;
+        MHPre<U> pre;
+        mh_ws_prefetch<NS, UV, U, NTV, true>(P, I, pre, Z.zs);
+        mh_ws_table<M>(P, S, I, NT, &tap0);
+        mh_ws_gp_store<M, K>(P, S, I, NT, gv);
+        __syncthreads();
+        mh_ws_run<NS, UV, false, U, M, false, true, NTV, true, true>(P, S, I, sweep, blockIdx.x, &pre, &Z,
+                                                                      item, zb);
+        return;
+    }
     const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
     D3D_MH_STAMP(blockIdx.x, 0, 0);
 #ifdef D3D_EXPERIMENTS
@@ -3617,11 +3741,21 @@ static __global__ __launch_bounds__(256) void k_rtnorm(long n, double lo, double
 // other than the next colour launch looks at it.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_flush_pending(MHArgs P) {
-    const int S = NT / P.HL;
-    const int s = threadIdx.x / P.HL, zl = threadIdx.x - s * P.HL;
     const int dw = P.dx1 - P.dx0;
-    const long cell = (long)blockIdx.x * S + s;  // cell of the domain, row-major
-    if (s >= S || cell >= (long)(P.dy1 - P.dy0) * dw) return;
+    int zl;
+    long cell;  // cell of the domain, row-major
+    if (P.HL > NT) {  // a spectrum longer than the workgroup: blockIdx.y counts its NT-thread pieces
+        zl = blockIdx.y * NT + threadIdx.x;
+        cell = blockIdx.x;
+        if (zl >= P.HL) return;
+    } else {
+        const int S = NT / P.HL;
+        const int s = threadIdx.x / P.HL;
+        zl = threadIdx.x - s * P.HL;
+        cell = (long)blockIdx.x * S + s;
+        if (s >= S) return;
+    }
+    if (cell >= (long)(P.dy1 - P.dy0) * dw) return;
     const int yy = P.dy0 + (int)(cell / dw), xx = P.dx0 + (int)(cell - (cell / dw) * dw);
     const long vox = (long)yy * P.W + xx;
     const int fhh = (P.fh - 1) / 2, fhw = (P.fw - 1) / 2;
@@ -3867,6 +4001,39 @@ static __global__ __launch_bounds__(1024) void k_mh_deep(MHArgs P, uint32_t swee
 
 // The proposals of one sweep for every unmasked spaxel of the rectangle [y0,y1) x [x0,x1)
 // (MHArgs::props), one thread per spaxel.
+// Z-blocked sweeps, second half of a colour class: one workgroup per window of the launch.
+// Totals the blocks' wave sums (block by block, wave by wave: a fixed order), takes the decision
+// (mh_decide_wave: accept, Gibbs draw, state), and forms the window's G row from the lines the
+// blocks left in z_E -- the pending layer the next colour's k_mh_ws<..., ZBK> applies.
+static __global__ __launch_bounds__(256) void k_mh_zdecide(MHArgs P, uint32_t sweep, int waves_per_block) {
+    extern __shared__ double smem[];
+    const int tid = threadIdx.x;
+    const int4 ent = P.spx[blockIdx.x];
+    if (!ent.z) return;  // a virtual position: it only applied pending layers
+    const int y = ent.x, x = ent.y, sp = y * P.W + x;
+    const int nw = P.z_nb * waves_per_block;
+    MHShared S = {};
+    S.sum = smem;                                                  // [nw][8] + the verdict
+    MHProposal *sq = reinterpret_cast<MHProposal *>(smem + (size_t)8 * nw + 8);
+    for (int i = tid; i < nw * 8; i += 256) S.sum[i] = P.z_part[(long)blockIdx.x * nw * 8 + i];
+    __syncthreads();
+    if (tid < 64) {
+        const MHProposal q = mh_proposal_of(P, sp, sweep);
+        const U2 u_gibbs = philox_pair(P.seed, q.gsp, sweep, BLK_GIBBS);
+        mh_decide_wave(P, S, q, sp, sweep, nw, u_gibbs);
+        if (tid == 0) *sq = q;
+    }
+    __syncthreads();
+    const double *verdict = S.sum + 8 * nw;
+    const bool accept = verdict[0] != 0.0;
+    const double r = verdict[1], a_old = sq->a_old;
+    const long slot = (long)(y / P.fh) * P.slots_x + x / P.fw;
+    const double *eo = P.z_E + slot * P.Dp, *en = eo + (long)P.z_slots * P.Dp;
+    double *g = P.Gcur + slot * P.Dp;
+    for (int ch = tid; ch < P.Dp; ch += 256)
+        g[ch] = (ch < P.D) ? residual_coeff(a_old, eo[ch], r, accept ? en[ch] : eo[ch]) : 0.0;
+}
+
 static __global__ __launch_bounds__(256) void k_mh_proposals(MHArgs P, uint32_t sweep, int y0, int y1,
                                                               int x0, int x1, MHProposal *out) {
     const int i = blockIdx.x * 256 + threadIdx.x;

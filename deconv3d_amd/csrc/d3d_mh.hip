@@ -52,6 +52,11 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.rev = 0;
     P.prio = c->mh_prio;
     P.props = nullptr;  // (run_part sets it for the parts whose colour launches are small)
+    P.z_part = c->z_part;
+    P.z_E = c->z_E;
+    P.z_db = 256;
+    P.z_nb = (c->Dp + P.z_db - 1) / P.z_db;
+    P.z_slots = (int)c->slots;
     for (int k = 0; k < 3; ++k) {
         P.min_b[k] = c->min_b[k];
         P.max_b[k] = c->max_b[k];
@@ -372,6 +377,74 @@ int launch_mh_pair(d3d_ctx *c, int ka, uint32_t sweep) {
 }
 #endif  // D3D_EXPERIMENTS
 
+// Cubes deeper than MH_WS_MAX_DP channels (taps within +-8 channels): one colour class in two
+// launches -- k_mh_ws<..., ZBK> on (window, 256-channel block) workgroups: the D = 256 kernel
+// on every block, up to the wave sums of the decision -- and k_mh_zdecide per window: totals,
+// accept, Gibbs draw, G row.  Deferred write-back and pending layers as in k_mh_ws.
+template <bool UV>
+int launch_mh_zb_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned n_items, uint32_t sweep, int layers) {
+    constexpr int NS = 256;
+    const int db = P.z_db;
+    const unsigned grid = n_items * (unsigned)P.z_nb;
+    const bool few = grid < (unsigned)c->flow_grid / 2;
+    hipError_t attr = hipSuccess;
+    auto go = [&](auto kern, int M) {
+        const size_t lds =
+            d3d::mh_ws_lds_doubles(NS, db / 2, db, db + 2 * d3d::LSF_RL, P.npos, M) * sizeof(double);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NS + 64), lds, c->stream, P, sweep);
+    };
+    // (the variants of a 256-channel cube: two pending layers, two positions in flight, the
+    // staged G rows in four registers; non-temporal 1/variance beyond the Infinity Cache)
+    const bool ntv = !UV && c->mh_nt_ivar && !few;
+    const int nl = P.n_lay;
+    if (layers >= 2) {
+        if (few) {
+            if (nl == 0) go(d3d::k_mh_ws<NS, UV, 4, 2, 4, 0, false, true>, 2);
+            else if (nl == 1) go(d3d::k_mh_ws<NS, UV, 4, 2, 4, 1, false, true>, 2);
+            else go(d3d::k_mh_ws<NS, UV, 4, 2, 4, 2, false, true>, 2);
+        } else if (ntv) {
+            if constexpr (!UV) {
+                if (nl == 0) go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 0, true, true>, 2);
+                else if (nl == 1) go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 1, true, true>, 2);
+                else go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 2, true, true>, 2);
+            }
+        } else {
+            if (nl == 0) go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 0, false, true>, 2);
+            else if (nl == 1) go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 1, false, true>, 2);
+            else go(d3d::k_mh_ws<NS, UV, 2, 2, 4, 2, false, true>, 2);
+        }
+    } else {
+        if (nl == 0) go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 0, false, true>, 1);
+        else go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 1, false, true>, 1);
+    }
+    HIP_TRY(attr);
+    HIP_TRY(hipGetLastError());
+    const int nw = P.z_nb * (NS / 64);
+    const size_t lds2 = ((size_t)8 * nw + 8 + 16) * sizeof(double);
+    hipLaunchKernelGGL(d3d::k_mh_zdecide, dim3(n_items), dim3(256), lds2, c->stream, P, sweep, NS / 64);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_mh_zb(d3d_ctx *c, d3d::MHArgs &P, unsigned n_items, uint32_t sweep, int layers) {
+    NEED(P.n_lay <= (layers >= 2 ? 2 : 1), D3D_ERR_STATE, "internal: %d pending layers for the z-blocked kernel",
+         P.n_lay);
+    // the blocks' wave sums of one launch and the lines of its updates
+    const size_t need = (size_t)n_items * P.z_nb * 32;
+    if (need > c->z_part_cap) {
+        if (c->z_part) HIP_TRY(hipFree(c->z_part));
+        c->z_part = nullptr;
+        c->z_part_cap = 0;
+        HIP_TRY(hipMalloc(&c->z_part, need * sizeof(double)));
+        c->z_part_cap = need;
+    }
+    if (!c->z_E) HIP_TRY(hipMalloc(&c->z_E, (size_t)2 * c->slots * c->Dp * sizeof(double)));
+    P.z_part = c->z_part;
+    P.z_E = c->z_E;
+    if (c->ivar_is_uniform && c->uniform_fast_path) return launch_mh_zb_t<true>(c, P, n_items, sweep, layers);
+    return launch_mh_zb_t<false>(c, P, n_items, sweep, layers);
+}
+
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
                     bool wide) {
     // wave-specialised kernel: 256 (or, above 256 channels, 512) streaming threads -- thread
@@ -418,8 +491,9 @@ int flush_pending(d3d_ctx *c) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<256>), dim3(grid), dim3(256), 0,
                                c->stream, P);
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>), dim3((unsigned)cells),
-                               dim3(1024), 0, c->stream, P);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_flush_pending<1024>),
+                               dim3((unsigned)cells, (unsigned)((c->HL + 1023) / 1024)), dim3(1024), 0,
+                               c->stream, P);
         }
         HIP_TRY(hipGetLastError());
     }

@@ -91,7 +91,7 @@ int d3d_timer_stop(d3d_ctx *ctx, double *elapsed_ms);
  * The environment variable D3D_<KEY> (upper case) only supplies a NEW ctx's default.
  * Changing an option flushes pending residual updates and re-derives what depends
  * on it (work lists, tap analysis), so it may be called at any time between calls.
- * Keys: mh_defer 0|1|2, mh_layers 0(auto)|1|2|3,
+ * Keys: mh_defer 0|1|2, mh_zblocks, mh_layers 0(auto)|1|2|3,
  * mh_wide, mh_props, halo_timing, mh_zigzag, mh_nt_ivar -1(auto)|0|1, mh_nt, uniform_ivar, conv_rows,
  * conv_zb, conv_hy, spatial_sep, sep_fuse, spatial_mode, march_hy, zmajor, zmajor_hy,
  * spectral_dense, spectral_blocks, spatial_nt, xcd_remap, alt_dir, stagger; a build with

@@ -55,6 +55,10 @@ def make_case(name):
         fsf = np.outer(O.gaussian_fsf_image(3.0)[:, 4], [0.25, 0.5, 0.25])
         fsf /= fsf.sum()
         lsf = O.gaussian_lsf_vector(D, 0.9088)
+    elif name == "tile_deep":   # tiling a cube beyond 512 channels: the z-blocked sweep kernels
+        D, H, W = 600, 26, 26
+        fsf = O.gaussian_fsf_image(2.0)                         # 7x7
+        lsf = O.muse_like_lsf(D)                                # taps within +-8 channels
     else:
         raise KeyError(name)
     y, x = np.indices((H, W))

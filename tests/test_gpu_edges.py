@@ -28,15 +28,20 @@ def small_problem(D, H, W, fsf, lsf, seed=0):
     return data, var, mask, truth, init, min_b, max_b
 
 
-@pytest.mark.parametrize("D", [100, 128, 200, 256, 257, 300, 512, 513, 1000, 1024, 1025, 2048, 3700])
-def test_deep_cubes_chain_matches_oracle(D):
+@pytest.mark.parametrize("D,lsf_kind", [(d, "gauss") for d in (100, 128, 200, 256, 257, 300, 512, 513, 1000,
+                                                                 1024, 1025, 2048, 3700)] +
+                         [(d, "muse") for d in (513, 770, 1024, 1025, 2048, 3700)])
+def test_deep_cubes_chain_matches_oracle(D, lsf_kind):
     """Depths that select every MH kernel: wave-specialised with 256 (D <= 256) or 512
     streaming threads (D <= 512), plain deferred beyond, 256/512/1024-thread blocks, the z-blocked forms beyond 1024
     channels (a full MUSE cube has ~3700; lib/convolution.py:137-141 takes any depth),
-    and non-power-of-two depths with the partial-wrap LSF."""
+    and non-power-of-two depths with the partial-wrap LSF.  "muse": LSF taps within +-8
+    channels -- beyond 512 channels the z-blocked form of the wave-specialised kernel
+    (k_mh_ws on 256-channel blocks + k_mh_zdecide); "gauss": a Gaussian's long tail of tiny
+    taps -- the plain deferred / thread-looped kernels there."""
     H, W = 5, 6
     fsf = O.gaussian_fsf_image(1.6)
-    lsf = O.gaussian_lsf_vector(D, 1.1)
+    lsf = O.gaussian_lsf_vector(D, 1.1) if lsf_kind == "gauss" else O.muse_like_lsf(D)
     data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=D)
     st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, seed=3)
     with _lib.Engine((D, H, W), fsf.shape) as eng:
@@ -79,6 +84,43 @@ def test_512_thread_wave_specialised_kernel_is_bit_identical_to_the_other_scheme
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("D,uniform", [(600, False), (1500, False), (1030, True)])
+def test_z_blocked_sweep_kernels_against_the_plain_ones(D, uniform):
+    """Cubes deeper than 512 channels: k_mh_ws on (window, 256-channel block) workgroups +
+    k_mh_zdecide (option mh_zblocks, default) -- one and two pending layers, per-voxel and
+    uniform variance, masked spaxels, a ragged last block -- against the plain kernels
+    (mh_zblocks = 0: k_mh_defer / k_mh_deep): another grouping of the channel sums, so to
+    rounding; the two layer depths of the z-blocked form bit for bit."""
+    H, W = 13, 12
+    fsf = O.gaussian_fsf_image(1.6)
+    lsf = O.muse_like_lsf(D)             # taps within +-8 channels: what the z-blocked form takes
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=D + 2)
+    if uniform:
+        var = np.full_like(var, 0.7)
+    outs = []
+    for opts in ({"mh_zblocks": 1}, {"mh_zblocks": 1, "mh_layers": 2}, {"mh_zblocks": 0}):
+        with _lib.Engine((D, H, W), fsf.shape, options=opts) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.set_data(data, var, mask=mask)
+            eng.set_params(init)
+            eng.mh_config(min_b, max_b, 0.1, 40.0, seed=3, refresh_every=0)
+            if uniform:
+                assert eng.variance_is_uniform()
+            assert eng.get_option("mh_zblocks") == opts["mh_zblocks"]
+            # (0: immediate write-back -- the thread-looped kernel of cubes beyond 1024 channels)
+            want = 2 if opts.get("mh_layers") == 2 else 1
+            assert eng.mh_layers() == (want if opts["mh_zblocks"] or D <= 1024 else 0)
+            acc = eng.mh_sweeps(3, 1)
+            outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), np.int64(acc)))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    live = mask == 1
+    np.testing.assert_allclose(outs[0][0][live], outs[2][0][live], rtol=1e-9, atol=1e-9)
+    assert np.max(np.abs(outs[0][1] - outs[2][1])) <= 1e-11 * np.max(np.abs(outs[2][1]))
+    assert outs[0][3] == outs[2][3]
+    np.testing.assert_array_equal(outs[0][0][~live], init[~live])
 
 
 def test_depth_limit_is_reported():
@@ -250,5 +292,5 @@ def test_pending_layer_policy():
     assert layers(64, 3) == 3
     assert layers(200, 3) == 2
     assert layers(300, 3) == 2          # 512 streaming threads (257 .. 512 channels)
-    assert layers(600, 3) == 1          # beyond: the plain deferred kernel, one layer
+    assert layers(600, 3) == 2          # beyond: the z-blocked form of the same kernel
 

@@ -59,7 +59,8 @@ def compare(case, lay, engines, ref_params, ref_err, exact=True):
 
 @pytest.mark.parametrize("name,grid,device_copy", [
     ("tile_a", (2, 2), True), ("tile_a", (4, 1), True), ("tile_a", (1, 2), False),
-    ("tile_b", (2, 3), True), ("tile_b", (2, 1), False), ("c1", (1, 1), True)])
+    ("tile_b", (2, 3), True), ("tile_b", (2, 1), False), ("c1", (1, 1), True),
+    ("tile_deep", (2, 1), True), ("tile_deep", (2, 2), True)])
 def test_tiled_chain_is_bit_identical_to_single_context(name, grid, device_copy):
     case = make_case(name)
     fh, fw = case["fsf"].shape
