@@ -224,7 +224,9 @@ int build_colour_lists(d3d_ctx *c) {
                 // XCD, whose L2 still holds its predecessor's window (64^3: 12.3 vs 12.6 us per
                 // launch with the lists reversed).
                 if (pt.real[col] > 0) {
-                    const int n_all_col = (int)list.size() - pt.off[col];
+                    // (the z-blocked kernels launch a workgroup per window AND 256-channel block)
+                    const long n_all_col =
+                        ((long)list.size() - pt.off[col]) * (c->mh_zb ? (c->Dp + 255) / 256 : 1);
                     if (c->mh_zigzag && (ord & 1) && n_all_col > c->flow_grid) {
                         std::reverse(list.begin() + pt.off[col], list.begin() + pt.off[col] + pt.real[col]);
                         std::reverse(list.begin() + pt.off[col] + pt.real[col], list.end());
@@ -236,7 +238,8 @@ int build_colour_lists(d3d_ctx *c) {
         pt.off[ncol] = (int)list.size();
         // Launches that do not fill the chip are latency chains: a second layer only adds
         // to their setup (64^3: 12.6 -> 13.0 us per colour), so they keep one.
-        pt.layers = (!c->mh_layers_forced && most < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
+        const long most_wgs = (long)most * (c->mh_zb ? (c->Dp + 255) / 256 : 1);
+        pt.layers = (!c->mh_layers_forced && most_wgs < c->flow_grid / 2) ? 1 : c->mh_layers_cfg;
         const bool partitioned = c->tiled || !c->part_rects.empty();
         pt.wide = pt.layers == 1 && c->mh_wide && partitioned && c->Dp == 128 && most > 0 &&
                   most <= c->flow_grid / 4 && c->mh_defer == 1;
@@ -1291,7 +1294,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         (void)pairs;
 #endif
         // small colour launches: the sweep's proposals come from one launch before them
-        const bool use_props = c->mh_props && pt.layers == 1 && !c->deep && !c->mh_zb && deferred;
+        // (and the z-blocked kernels: every block's prepare wavefront and k_mh_zdecide need it)
+        const bool use_props =
+            c->mh_props && deferred && (c->mh_zb || (pt.layers == 1 && !c->deep));
         if (use_props)
             if (int rc = ensure_proposals(c, sweep)) return rc;
         d3d::MHArgs P;

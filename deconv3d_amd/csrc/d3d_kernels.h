@@ -4030,8 +4030,28 @@ static __global__ __launch_bounds__(256) void k_mh_zdecide(MHArgs P, uint32_t sw
     const long slot = (long)(y / P.fh) * P.slots_x + x / P.fw;
     const double *eo = P.z_E + slot * P.Dp, *en = eo + (long)P.z_slots * P.Dp;
     double *g = P.Gcur + slot * P.Dp;
-    for (int ch = tid; ch < P.Dp; ch += 256)
-        g[ch] = (ch < P.D) ? residual_coeff(a_old, eo[ch], r, accept ? en[ch] : eo[ch]) : 0.0;
+    // (z-pairs, four per thread in flight: the loop is a chain of memory latencies otherwise)
+    for (int z0 = 2 * tid; z0 < P.Dp; z0 += 4 * 512) {
+        double2 a[4], b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = z0 + k * 512;
+            a[k] = b[k] = make_double2(0.0, 0.0);
+            if (z < P.Dp) {
+                a[k] = *reinterpret_cast<const double2 *>(eo + z);
+                if (accept) b[k] = *reinterpret_cast<const double2 *>(en + z);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int z = z0 + k * 512;
+            if (z >= P.Dp) continue;
+            double2 o;
+            o.x = (z < P.D) ? residual_coeff(a_old, a[k].x, r, accept ? b[k].x : a[k].x) : 0.0;
+            o.y = (z + 1 < P.D) ? residual_coeff(a_old, a[k].y, r, accept ? b[k].y : a[k].y) : 0.0;
+            *reinterpret_cast<double2 *>(g + z) = o;
+        }
+    }
 }
 
 static __global__ __launch_bounds__(256) void k_mh_proposals(MHArgs P, uint32_t sweep, int y0, int y1,
