@@ -307,9 +307,13 @@ def measured_traffic(kernel_prefix, workload):
             continue
         if rec.get("workload") != workload:
             continue
-        for k, v in rec.get("hbm_bytes_per_launch", {}).items():
-            if k.split("::")[-1].startswith(kernel_prefix):
-                best = int(v) if rec.get("source_hash") == _lib.source_hash() else "stale"
+        # (the launch-weighted mean over the kernel's pending-layer variants, "..., *, ...", where
+        # the summary has one: tools/summarize_profile.py)
+        hits = [(k, v) for k, v in rec.get("hbm_bytes_per_launch", {}).items()
+                if k.split("::")[-1].startswith(kernel_prefix)]
+        fam = [kv for kv in hits if ", *" in kv[0]]
+        for k, v in (fam or hits):
+            best = int(v) if rec.get("source_hash") == _lib.source_hash() else "stale"
     return best
 
 

@@ -58,7 +58,7 @@ for s in stats:
 # bench.py's launch average is the launch-weighted mean over the family.
 families = collections.OrderedDict()
 for r in rows:
-    if r["kernel"].startswith("d3d::k_mh_ws<") and r["kernel"].count(",") == 6:
+    if r["kernel"].startswith("d3d::k_mh_ws<") and r["kernel"].count(",") >= 6:
         args = r["kernel"][len("d3d::k_mh_ws<"):-1].split(", ")
         args[5] = "*"                      # the pending-layer count
         families.setdefault("d3d::k_mh_ws<" + ", ".join(args) + ">", []).append(r)
