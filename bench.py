@@ -58,6 +58,9 @@ WORKLOADS = {
     # config 3's footprint and taps at other depths (the convolution kernels' other forms)
     "d64_300x300x64": (64, 300, 300, 11),
     "d256_300x300x256": (256, 300, 300, 11),
+    # the 512-thread form of the sweep kernel, and its z-blocked form (a MUSE cube's depth class)
+    "d512_300x300x512": (512, 300, 300, 11),
+    "d1024_300x300x1024": (1024, 300, 300, 11),
 }
 
 
