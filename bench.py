@@ -243,6 +243,7 @@ def start_tiled_leg(args, rank):
     import tempfile
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29500")) + TILED_LEG_PORT_OFFSET)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: RCCL between processes needs it here)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(args.gpus), "--mode", "tiled",
            "--steps", str(min(args.steps, 50)), "--warmup", str(min(max(args.warmup, 1), 3)),
            "--workload", args.workload, "--backend", args.backend, "--wait-stdin"]
