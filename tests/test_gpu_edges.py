@@ -123,6 +123,31 @@ def test_z_blocked_sweep_kernels_against_the_plain_ones(D, uniform):
     np.testing.assert_array_equal(outs[0][0][~live], init[~live])
 
 
+@pytest.mark.parametrize("D,H,W", [(700, 30, 28), (2100, 14, 25)])
+def test_z_blocked_chain_carries_its_residual(D, H, W):
+    """lib/run.py:521-534 on the z-blocked kernels: after 20 sweeps, split over three calls with
+    a periodic from-scratch residual in between, the carried residual equals the one rebuilt
+    from the parameters (only ~1e-14 of creep), with and without the refresh."""
+    fsf = O.gaussian_fsf_image(1.6)
+    lsf = O.muse_like_lsf(D)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=5)
+    outs = []
+    for every in (0, 7):
+        with _lib.Engine((D, H, W), fsf.shape, options={"mh_layers": 2}) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.set_data(data, var, mask=mask)
+            eng.set_params(init)
+            eng.mh_config(min_b, max_b, 0.1, 40.0, seed=11, refresh_every=every)
+            eng.mh_sweeps(6, 1)
+            eng.mh_sweeps(9, 7)
+            eng.mh_sweeps(5, 16)
+            carried = eng.download_slot(_lib.SLOT_ERR)
+            fresh = eng.residual()
+            assert np.max(np.abs(carried - fresh)) <= 1e-11 * np.max(np.abs(fresh))
+            outs.append(eng.get_params())
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-8, atol=1e-8)
+
+
 def test_depth_limit_is_reported():
     with pytest.raises(NotImplementedError, match="8192"):
         _lib.Engine((8193, 4, 4), (3, 3))
