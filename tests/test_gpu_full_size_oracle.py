@@ -158,6 +158,33 @@ def test_512_thread_kernel_with_chip_filling_launches_matches_the_oracle():
         np.testing.assert_array_equal(a, b)
 
 
+def test_z_blocked_kernels_with_chip_filling_launches():
+    """Beyond 512 channels with launches that fill the chip (1100 channels = 5 blocks, 121
+    windows per colour class: 605 workgroups): the two-layer form of the z-blocked kernels under
+    both cache policies -- bit-identical --, against the thread-looped kernel of deep cubes
+    (mh_zblocks = 0) to rounding, and the carried residual against the one rebuilt from the
+    parameters."""
+    outs = []
+    for opts in ({"mh_nt_ivar": 0}, {"mh_nt_ivar": 1}, {"mh_zblocks": 0}):
+        eng, pb = build(1100, 112, 112, 11, options=opts)
+        with eng:
+            if "mh_nt_ivar" in opts:
+                assert eng.mh_layers() == 2
+            start(eng, pb)
+            accepted = eng.mh_sweeps(3, 1)
+            carried = eng.download_slot(_lib.SLOT_ERR)
+            params = eng.get_params()
+            fresh = eng.residual()
+            assert np.max(np.abs(carried - fresh)) <= 1e-11 * np.max(np.abs(fresh))
+            outs.append((params, eng.get_dlog(), carried, np.int64(accepted)))
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_array_equal(a, b)
+    live = pb["mask"] == 1
+    np.testing.assert_allclose(outs[0][0][live], outs[2][0][live], rtol=1e-9, atol=1e-9)
+    assert np.max(np.abs(outs[0][2] - outs[2][2])) <= 1e-11 * np.max(np.abs(outs[2][2]))
+    assert outs[0][3] == outs[2][3]
+
+
 @pytest.mark.parametrize("shape", [(64, 64, 64), (128, 150, 90)])
 def test_zigzag_walk_off_and_on_match_the_oracle(shape):
     """Option mh_zigzag: every other colour class walks its window positions backwards.
