@@ -387,8 +387,8 @@ int launch_mh_zb_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned n_items, uint32_t 
     const int db = P.z_db;
     const unsigned grid = n_items * (unsigned)P.z_nb;
     const bool few = grid < (unsigned)c->flow_grid / 2;
-    hipError_t attr = hipSuccess;
     auto go = [&](auto kern, int M) {
+        // (LDS of the 256-channel kernel: 35-40 KB, four workgroups per CU)
         const size_t lds =
             d3d::mh_ws_lds_doubles(NS, db / 2, db, db + 2 * d3d::LSF_RL, P.npos, M) * sizeof(double);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NS + 64), lds, c->stream, P, sweep);
@@ -417,7 +417,6 @@ int launch_mh_zb_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned n_items, uint32_t 
         if (nl == 0) go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 0, false, true>, 1);
         else go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 1, false, true>, 1);
     }
-    HIP_TRY(attr);
     HIP_TRY(hipGetLastError());
     const int nw = P.z_nb * (NS / 64);
     const size_t lds2 = ((size_t)8 * nw + 8 + 16) * sizeof(double);
