@@ -40,9 +40,11 @@ def draw_case(seed, depth=None, extent=34):
         fsf /= fsf.sum()
     else:
         fsf = np.ones((1, 1))
-    lkind = rng.choice(["none", "gauss", "wide", "dense"])
+    lkind = rng.choice(["none", "gauss", "wide", "dense"] + (["muse", "muse"] if D > 130 else []))
     if lkind == "none":
         lsf = None
+    elif lkind == "muse":
+        lsf = O.muse_like_lsf(D)                                          # taps within +-8 channels
     elif lkind == "gauss":
         lsf = O.gaussian_lsf_vector(D, float(rng.uniform(0.3, 1.2)))
     elif lkind == "wide":
@@ -81,6 +83,16 @@ def test_random_shape_at_depth_128_matches_oracle(seed128):
 @pytest.fixture(params=range(10))
 def seed128(request):
     return request.param
+
+
+@pytest.mark.parametrize("seed,depth", [(s, d) for s, d in enumerate(
+    [200, 264, 300, 512, 520, 700, 770, 1030, 1100, 2100, 257, 640])])
+def test_random_shape_at_greater_depths_matches_oracle(seed, depth):
+    """Depths beyond 128 channels: the z-blocked FSF pass, the LSF pass in 128-channel blocks, the
+    512-thread sweep kernel (257 .. 512 channels) and, for LSF taps within +-8 channels, the
+    z-blocked sweep kernels beyond -- on drawn footprints, FSF classes, LSF kinds, masks and
+    variances."""
+    check_case(draw_case(900 + seed, depth=depth, extent=22), seed)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("D3D_TEST_RANDOM_SHAPES", "32"))))
