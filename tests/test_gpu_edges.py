@@ -178,6 +178,38 @@ def test_deep_cube_probe_convolution_and_run():
         np.testing.assert_allclose(cmap, 0.5 * np.sum(err ** 2 / var, axis=0), rtol=1e-10)
 
 
+def test_z_blocked_context_between_sweeps_probe_and_chi2_flush_the_pending_layers():
+    """A 700-channel context (z-blocked sweep kernels, two pending layers forced): the window
+    probe and the chi2 map in the middle of a chain see the residual with every pending update
+    applied, and the chain goes on as if nothing had happened -- all against the oracle."""
+    D, H, W = 700, 8, 9
+    fsf = O.gaussian_fsf_image(1.6)
+    lsf = O.muse_like_lsf(D)
+    data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=21)
+    st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, seed=4)
+    with _lib.Engine((D, H, W), fsf.shape, options={"mh_layers": 2}) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_data(data, var, mask=mask)
+        eng.set_params(init)
+        eng.mh_config(min_b, max_b, 0.1, st.ra, seed=4, refresh_every=0)
+        assert eng.mh_layers() == 2
+        eng.mh_sweeps(2, 1)
+        for s_ in (1, 2):
+            O.mh_sweep(st, s_)
+        y, x = np.argwhere(mask == 1)[3]
+        p_new = st.params[y, x] + np.array([0., 0.9, 0.15])
+        got = eng.window_stats(int(y), int(x), p_new)
+        want = O.window_stats(st.err, var, st.params[y, x], p_new, int(y), int(x), fsf, lsf)
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11 * abs(want[0]))
+        cmap, total = eng.chi2_map()
+        np.testing.assert_allclose(cmap, 0.5 * np.sum(st.err ** 2 / var, axis=0), rtol=1e-9)
+        eng.mh_sweeps(1, 3)
+        O.mh_sweep(st, 3)
+        np.testing.assert_allclose(eng.get_params(), st.params, rtol=1e-9, atol=1e-9)
+        err = eng.download_slot(_lib.SLOT_ERR)
+        assert np.max(np.abs(err - st.err)) <= 1e-11 * np.max(np.abs(st.err))
+
+
 def test_nan_voxels_and_zero_variance():
     """NaN voxels get zero weight (nansum of lib/run.py:423-424), a spaxel with a
     NaN anywhere in its spectrum is never iterated (lib/run.py:159-162), zero
