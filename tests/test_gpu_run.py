@@ -123,6 +123,45 @@ def test_run_end_to_end_config1():
     assert (run.chain[..., 2] >= 0).all() and (run.chain[..., 2] <= 32).all()
 
 
+def test_run_end_to_end_on_a_deep_cube_with_the_muse_lsf():
+    """Run() on a 600-channel cube with MUSELineSpreadFunction's analytic stand-in (taps
+    within +-8 channels): the z-blocked sweep kernels, the blocked LSF pass and the z-blocked
+    FSF pass behind the reference's API -- streamed chain, fit quality, bounds."""
+    D, H, W = 600, 12, 11
+    inst = d3d.MUSE(lsf=d3d.MUSELineSpreadFunction(model="analytic"), fsf_fwhm=0.6)
+    rng = np.random.default_rng(5)
+    y, x = np.indices((H, W))
+    r2 = (y - H / 2.) ** 2 + (x - W / 2.) ** 2
+    truth = np.dstack((10.0 * np.exp(-r2 / (2. * (H / 5.) ** 2)),
+                       D / 2. + (D / 10.) * np.tanh((x - W / 2.) / (W / 6.)),
+                       rng.uniform(1.5, 3.0, size=(H, W))))
+    blank = inst.build_cube(np.ones((D, H, W)))
+    fsf, lsf = inst.fsf.as_image(blank), inst.lsf.as_vector(blank)
+    with _lib.Engine((D, H, W), fsf.shape) as eng:
+        eng.set_taps(fsf, lsf)
+        eng.set_params(truth)
+        clean = eng.forward()
+        assert eng.get_option("mh_zblocks") == 1
+    sigma = 0.05 * 10.0 * fsf.max()
+    data = clean + rng.normal(0., sigma, size=clean.shape)
+    var = np.full(clean.shape, sigma ** 2) * (0.5 + rng.random(clean.shape))
+    # (a 0.5-channel random walk does not find a line among 600 channels in a test's time:
+    # start near it, as a user of a deep cube would -- initial_parameters, lib/run.py:290-312)
+    start = truth + np.dstack((rng.normal(0., 1., (H, W)), rng.normal(0., 3., (H, W)),
+                               rng.normal(0., 0.3, (H, W))))
+    start[..., 0] = np.abs(start[..., 0])
+    run = d3d.Run(inst.build_cube(data), inst, variance=var, max_iterations=120, keep_one_in=3,
+                  jump_amplitude=[0., 0.5, 0.2], initial_parameters=start, seed=2)
+    assert run.chain.shape == (40, H, W, 3) and not np.isnan(run.chain).any()
+    assert 0.0 < run.acceptance_rate <= 1.0
+    run.engine.set_params(run.chain[-1])
+    err = run.engine.residual()
+    assert np.sum(err ** 2 / var) / err.size < 2.0
+    bright = truth[..., 0] > 5.0
+    assert np.median(np.abs(run.parameters[..., 1] - truth[..., 1])[bright]) < 2.0
+    assert (run.chain[..., 0] >= 0).all() and (run.chain[..., 2] <= D).all()
+
+
 def test_run_is_reproducible_and_seed_sensitive():
     inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
     a = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)
