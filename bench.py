@@ -23,6 +23,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
   roofline             -- the MH sweep kernel (k_mh_ws): algorithmic bytes / launch time
   roofline_beyond_mall -- the same kernel on a 300x300x256 cube, whose residual +
                           1/variance (369 MB) exceed the 256 MB Infinity Cache
+  roofline_deep        -- the sweep on a 200x200x1024 cube: the z-blocked form of the kernel
+                          (one workgroup per window and 256-channel block + a decision launch)
   roofline_conv        -- the separable LSF (x) FSF convolution of one cube
   cpu_baseline         -- the oracle's memory-sane numpy update loop on the host cores
   cpu_baseline_conv    -- the oracle's LSF (x) FSF convolution of one cube on the host
@@ -290,7 +292,7 @@ def finish_tiled_leg(leg, rank):
     return {"error": "tiled leg exited with code %s" % proc.returncode, "stderr_tail": tail}
 
 
-def measured_traffic(kernel_prefix, workload):
+def measured_traffic(kernel_prefix, workload, kernel_suffix=""):
     """HBM bytes per launch from the committed rocprofv3 PMC passes
     (tools/profile_round.sh -> profiles/<tag>_traffic.json: 2 x FETCH_SIZE KiB
     [gfx950 correction] + WRITE_SIZE KiB, separate passes).  None if no profile on
@@ -314,7 +316,7 @@ def measured_traffic(kernel_prefix, workload):
         # (the launch-weighted mean over the kernel's pending-layer variants, "..., *, ...", where
         # the summary has one: tools/summarize_profile.py)
         hits = [(k, v) for k, v in rec.get("hbm_bytes_per_launch", {}).items()
-                if k.split("::")[-1].startswith(kernel_prefix)]
+                if k.split("::")[-1].startswith(kernel_prefix) and k.endswith(kernel_suffix)]
         fam = [kv for kv in hits if ", *" in kv[0]]
         for k, v in (fam or hits):
             best = int(v) if rec.get("source_hash") == _lib.source_hash() else "stale"
@@ -332,8 +334,24 @@ def beyond_mall_leg(args, local_rank, fs):
     """The MH kernel on a 300x300x256 cube: residual + 1/variance = 369 MB, more
     than the 256 MB Infinity Cache (MALL), so the stream cannot be cache-served as
     the 184 MB working set of the headline cube partly is.  Priced like `roofline`."""
+    return mh_cube_leg(args, local_rank, fs, (256, 300, 300),
+                       "k_mh_ws, 300x300x256 cube (working set 369 MB > 256 MB MALL)",
+                       ("k_mh_ws<256, false, 2, 2, 4,", "true, false>"))
+
+
+def deep_leg(args, local_rank, fs):
+    """The sweep on a cube beyond the 512 channels one workgroup takes: 200x200x1024 (655 MB of
+    residual + 1/variance) -- k_mh_ws on (window, 256-channel block) workgroups + k_mh_zdecide
+    per window, two launches per colour class.  Priced like `roofline`; avg_launch_us is the
+    PAIR of launches of one colour class."""
+    return mh_cube_leg(args, local_rank, fs, (1024, 200, 200),
+                       "k_mh_ws<..., ZBK> + k_mh_zdecide, 200x200x1024 cube (z-blocks of 256 channels)",
+                       ("k_mh_ws<256, false, 2, 2, 4,", "true, true>"))
+
+
+def mh_cube_leg(args, local_rank, fs, shape, label, traffic_key):
     from deconv3d_amd import _lib
-    D, H, W = 256, 300, 300
+    D, H, W = shape
     fsf, lsf = build_taps(D, fs)
     steps = max(2, min(args.steps, 10))
     with _lib.Engine((D, H, W), fsf.shape, device=local_rank) as eng:
@@ -354,11 +372,11 @@ def beyond_mall_leg(args, local_rank, fs):
         bytes_per_launch = 3 * 8 * D * window_voxels(H, W, fh, fw) // ncol
         us = ms * 1e3 / (ncol * steps)
         gbs = bytes_per_launch / (us * 1e-6) / 1e9
-        return {"kernel": "k_mh_ws, 300x300x256 cube (working set 369 MB > 256 MB MALL)",
+        return {"kernel": label,
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
                 # (the committed profile's command runs this leg too: same file, same run)
-                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 4,", args.workload),
+                "traffic": measured_traffic(traffic_key[0], args.workload, traffic_key[1]),
                 "bytes_per_launch": bytes_per_launch, "avg_launch_us": round(us, 2),
                 "launches": ncol * steps, "residual_written_every": eng.mh_layers(),
                 "value": round(steps * H * W / (ms * 1e-3), 1), "unit_value": "spaxel-updates/s"}
@@ -408,6 +426,8 @@ def main():
     ap.add_argument("--no-conv-beyond-mall", action="store_true",
                     help="skip the 600x600x128 convolution leg (tools/profile_round.sh: it runs the "
                          "same kernel as `roofline_conv` and would mix into its counter averages)")
+    ap.add_argument("--no-deep", action="store_true",
+                    help="skip the 200x200x1024 leg (the z-blocked sweep kernels of cubes beyond 512 channels)")
     ap.add_argument("--tiles", default=None,
                     help="--mode tiled: tile grid TYxTX (default: row strips, N x 1); with "
                          "--gpus 1 the tiles run as contexts of this one process (loop-back)")
@@ -548,7 +568,7 @@ def main():
     roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload, "false, false>"),
                 "bytes_per_launch": bytes_per_sweep // ncol,
                 "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
                 # `achieved` prices the 24 B per window voxel of SURVEY 8(d) (read residual,
@@ -647,6 +667,8 @@ def main():
         out["host"] = host_info()
     if rank == 0 and not args.no_extras and args.workload == "c3_300x300x128":
         out["roofline_beyond_mall"] = beyond_mall_leg(args, local_rank, fs)
+        if not args.no_deep:
+            out["roofline_deep"] = deep_leg(args, local_rank, fs)
         if not args.no_conv_beyond_mall:
             out["roofline_conv_beyond_mall"] = conv_beyond_mall_leg(args, local_rank, fs)
     if rank == 0 and not args.no_extras:
@@ -670,7 +692,7 @@ def main():
                 "bytes_per_launch": bytes_per_sweep * 2 // 3 // ncol,
                 "avg_launch_us": round(u_us, 2), "achieved": round(u_gbs, 1),
                 "frac": round(u_gbs / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, true, 4, 2, 2,", args.workload),
+                "traffic": measured_traffic("k_mh_ws<256, true, 4, 2, 2,", args.workload, "false, false>"),
                 "note": "extra: reference default variance=None (one constant); not `value`"}
 
     if rank == 0 and not args.no_extras:
