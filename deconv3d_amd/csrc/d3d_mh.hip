@@ -428,12 +428,13 @@ int launch_mh_zb_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned n_items, uint32_t 
 int launch_mh_zb(d3d_ctx *c, d3d::MHArgs &P, unsigned n_items, uint32_t sweep, int layers) {
     NEED(P.n_lay <= (layers >= 2 ? 2 : 1), D3D_ERR_STATE, "internal: %d pending layers for the z-blocked kernel",
          P.n_lay);
-    // the blocks' wave sums of one launch and the lines of its updates
-    const size_t need = (size_t)n_items * P.z_nb * 32;
-    if (need > c->z_part_cap) {
-        if (c->z_part) HIP_TRY(hipFree(c->z_part));
-        c->z_part = nullptr;
-        c->z_part_cap = 0;
+    // the blocks' wave sums of one launch and the lines of its updates.  A launch's windows
+    // are distinct points of one colour class's lattice, up to one period outside the cube:
+    // allocated once, for the largest launch there can be
+    const size_t max_items = (size_t)(c->H / c->fh + 2) * (c->W / c->fw + 2);
+    NEED((size_t)n_items <= max_items, D3D_ERR_STATE, "internal: %u windows in one colour launch", n_items);
+    if (!c->z_part) {
+        const size_t need = max_items * P.z_nb * 32;
         HIP_TRY(hipMalloc(&c->z_part, need * sizeof(double)));
         c->z_part_cap = need;
     }
