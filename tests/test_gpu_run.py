@@ -162,6 +162,44 @@ def test_run_end_to_end_on_a_deep_cube_with_the_muse_lsf():
     assert (run.chain[..., 0] >= 0).all() and (run.chain[..., 2] <= D).all()
 
 
+def test_concurrent_chains_on_one_gpu_are_the_chains_they_would_be_alone():
+    """deconv3d_amd.ensemble.sweep_chains: four contexts of one process, one host thread
+    each, their colour launches overlapping on the device -- every chain, its streamed
+    samples and its accepted count equal the same context run alone, bit for bit."""
+    from deconv3d_amd import ensemble
+    from tests.cases import make_case
+    case = make_case("c1")
+    D, H, W = case["D"], case["H"], case["W"]
+
+    def make(seed):
+        eng = _lib.Engine((D, H, W), case["fsf"].shape)
+        eng.set_taps(case["fsf"], case["lsf"])
+        eng.set_data(case["data"], case["var"], mask=case["mask"])
+        eng.set_params(case["init"])
+        eng.mh_config(case["min_b"], case["max_b"], 0.1, 40.0, seed=seed, refresh_every=0)
+        return eng
+
+    n = 12
+    alone = []
+    for seed in (1, 2, 3, 4):
+        with make(seed) as eng:
+            chain = np.full((n + 1, H, W, 3), np.nan)
+            acc = eng.mh_sweeps(n, 1, 1, chain, None)
+            alone.append((chain, acc, eng.download_slot(_lib.SLOT_ERR)))
+    engs = [make(seed) for seed in (1, 2, 3, 4)]
+    try:
+        chains = [np.full((n + 1, H, W, 3), np.nan) for _ in engs]
+        accs = ensemble.sweep_chains(engs, n, 1, 1, chains)
+        for i, eng in enumerate(engs):
+            np.testing.assert_array_equal(chains[i][1:], alone[i][0][1:])
+            assert accs[i] == alone[i][1]
+            np.testing.assert_array_equal(eng.download_slot(_lib.SLOT_ERR), alone[i][2])
+        assert not np.array_equal(chains[0][-1], chains[1][-1])
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_run_is_reproducible_and_seed_sensitive():
     inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
     a = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)
