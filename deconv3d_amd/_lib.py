@@ -30,7 +30,7 @@ SYMBOLS = [
     "d3d_mh_config", "d3d_mh_set_sweep_origin", "d3d_window_stats",
     "d3d_mh_sweeps", "d3d_mh_colour_lines", "d3d_get_dlog", "d3d_variance_is_uniform", "d3d_mh_layers",
     "d3d_colour_count", "d3d_rtnorm",
-    "d3d_set_tile", "d3d_set_parts", "d3d_mh_phase", "d3d_mh_accepted", "d3d_flush",
+    "d3d_set_tile", "d3d_set_parts", "d3d_mh_phase", "d3d_mh_sweeps_batch", "d3d_mh_accepted", "d3d_flush",
     "d3d_halo_plan", "d3d_comm_unique_id", "d3d_comm_init", "d3d_comm_destroy", "d3d_comm_info",
     "d3d_halo_time",
     "d3d_halo_exchange", "d3d_halo_pack", "d3d_halo_unpack", "d3d_halo_buffers",
@@ -121,6 +121,7 @@ def load():
     int_p = C.POINTER(C.c_int)
     lib.d3d_set_parts.argtypes = [ctx_p, C.c_int, int_p, int_p]
     lib.d3d_mh_phase.argtypes = [ctx_p, C.c_int, C.c_int]
+    lib.d3d_mh_sweeps_batch.argtypes = [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
     lib.d3d_mh_accepted.argtypes = [ctx_p, C.POINTER(C.c_int64), C.c_int]
     lib.d3d_flush.argtypes = [ctx_p]
     lib.d3d_halo_plan.argtypes = [ctx_p, C.c_int, C.c_int, int_p]
@@ -165,6 +166,17 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_UID_BYTES)
     _check(load().d3d_comm_unique_id(C.cast(buf, C.c_void_p)))
     return buf.raw
+
+
+def mh_sweeps_batch(engines, n_sweeps, first_sweep=1):
+    """d3d_mh_sweeps_batch: the chains of several Engines of one geometry, one launch per colour
+    class for all of them.  Returns the accepted counts, one per engine."""
+    lib = load()
+    n = len(engines)
+    arr = (C.c_void_p * n)(*[e._ctx.value for e in engines])
+    acc = (C.c_int64 * n)()
+    _check(lib.d3d_mh_sweeps_batch(arr, n, int(n_sweeps), int(first_sweep), acc))
+    return [int(v) for v in acc]
 
 
 def device_count():

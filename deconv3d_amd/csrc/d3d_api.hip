@@ -1477,6 +1477,35 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     return D3D_OK;
 }
 
+int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int64_t *accepted) {
+    NEED(ctxs && n_ctx >= 1, D3D_ERR_INVALID, "no contexts");
+    NEED(n_sweeps >= 0 && first_sweep >= 0, D3D_ERR_INVALID, "negative sweep count/index");
+    d3d_ctx *L = ctxs[0];
+    for (int r = 0; r < n_ctx; ++r) {
+        d3d_ctx *c = ctxs[r];
+        NEED(c, D3D_ERR_INVALID, "ctx %d is NULL", r);
+        for (int q = 0; q < r; ++q) NEED(ctxs[q] != c, D3D_ERR_INVALID, "ctx %d appears twice", r);
+        NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,
+             "ctx %d: taps/data/parameters/mh_config not set", r);
+        NEED(!c->tiled && c->parts.size() == 1 && !c->comm, D3D_ERR_UNSUPPORTED,
+             "ctx %d is tiled or partitioned: batched chains are whole cubes", r);
+        NEED(c->mh_defer == 1 && c->Dp <= 256 && !c->deep, D3D_ERR_UNSUPPORTED,
+             "ctx %d: batched chains take cubes up to 256 channels with the default write-back scheme", r);
+        NEED(c->device == L->device && c->D == L->D && c->H == L->H && c->W == L->W && c->fh == L->fh &&
+                 c->fw == L->fw,
+             D3D_ERR_INVALID, "ctx %d: another device or shape than ctx 0", r);
+        NEED(c->h_mask == L->h_mask && c->h_fsf == L->h_fsf && c->h_has_lsf == L->h_has_lsf &&
+                 (!c->h_has_lsf || c->h_lsf == L->h_lsf) && c->h_thr == L->h_thr,
+             D3D_ERR_INVALID, "ctx %d: another mask, FSF or LSF than ctx 0 (the chains share the work lists and taps)", r);
+        NEED((c->ivar_is_uniform && c->uniform_fast_path) == (L->ivar_is_uniform && L->uniform_fast_path),
+             D3D_ERR_INVALID, "ctx %d: uniform and per-voxel variances cannot share a launch", r);
+        NEED(c->mh_zigzag == L->mh_zigzag && c->sweep_origin == L->sweep_origin, D3D_ERR_INVALID,
+             "ctx %d: another walk order or sweep origin than ctx 0", r);
+    }
+    HIP_TRY(hipSetDevice(L->device));
+    return mh_sweeps_batch(ctxs, n_ctx, n_sweeps, first_sweep, accepted);
+}
+
 int d3d_mh_phase(d3d_ctx *c, int phase, int sweep) {
     NEED(c, D3D_ERR_INVALID, "ctx is NULL");
     NEED(c->have_taps && c->have_data && c->have_params && c->have_cfg, D3D_ERR_STATE,

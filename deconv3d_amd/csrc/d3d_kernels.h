@@ -1558,6 +1558,17 @@ static __global__ __launch_bounds__(1024) void k_sum(const double *__restrict__ 
 //               per sweep (opt-in).
 
 struct MHProposal;
+struct MHChainArgs {  // one chain of a batch: see MHArgs::batch
+    double *err;
+    const double *ivar;
+    double ivar_uniform;
+    double *params, *prev, *dlog;
+    unsigned long long *accepted;
+    double *gbuf[4];
+    double min_b[3], max_b[3], amp[3];
+    double ra;
+    uint64_t seed;
+};
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;
     double *err;
@@ -1637,6 +1648,11 @@ struct MHArgs {
     double *z_part;
     double *z_E;
     int z_nb, z_db, z_slots;
+    // Batched chains (k_mh_ws<..., BATCH>, d3d_mh_sweeps_batch): R chains of one geometry in ONE
+    // launch per colour class, grid = R x b_items; `batch` holds what differs between them, the
+    // G buffers by index (all chains rotate theirs alike).
+    const struct MHChainArgs *batch;
+    int b_items, b_gcur, b_lay_g[3];
     // Staggered completion (EXPERIMENTS builds, option mh_prio; mh_stagger): half of a
     // colour's windows finish streaming before the other half, so that their decisions
     // overlap the others' streams (measured flat: DESIGN.md section 3).
@@ -2722,10 +2738,39 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
 // channels; a workgroup runs the kernel on ITS block -- the arguments' counts and pointers are
 // rewritten to describe the block alone, only the spaxel stride stays the cube's -- up to the
 // wave sums of the decision, which k_mh_zdecide totals over the blocks.
-template <int NS, bool UV, int U, int M, int K, int NL = -1, bool NTV = false, bool ZBK = false>
+// BATCH (round 3): the launch holds the windows of R independent chains of one geometry
+// (chain-major); the chain's cubes, parameters, bounds and random stream replace the
+// arguments' -- everything else (work list, taps, pending-layer geometry) is common.
+template <int NS, bool UV, int U, int M, int K, int NL = -1, bool NTV = false, bool ZBK = false,
+          bool BATCH = false>
 __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     constexpr int NT = NS + 64;
+    static_assert(!(ZBK && BATCH), "batched chains: cubes of one workgroup per window");
+    int item = blockIdx.x;
+    if constexpr (BATCH) {
+        const int r = blockIdx.x / P.b_items;
+        item = blockIdx.x - r * P.b_items;
+        const MHChainArgs &B = P.batch[r];
+        P.err = B.err;
+        P.ivar = B.ivar;
+        P.ivar_uniform = B.ivar_uniform;
+        P.params = B.params;
+        P.prev = B.prev;
+        P.dlog = B.dlog;
+        P.accepted = B.accepted;
+        P.Gcur = B.gbuf[P.b_gcur];
+#pragma unroll
+        for (int j = 0; j < MH_LAYERS; ++j) P.lay_G[j] = B.gbuf[P.b_lay_g[j]];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            P.min_b[k] = B.min_b[k];
+            P.max_b[k] = B.max_b[k];
+            P.amp[k] = B.amp[k];
+        }
+        P.ra = B.ra;
+        P.seed = B.seed;
+    }
     if constexpr (ZBK) {
         const int item = blockIdx.x / P.z_nb, zb = blockIdx.x - item * P.z_nb;
         MHZ Z;
@@ -2773,7 +2818,7 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
 #ifdef D3D_EXPERIMENTS
     mh_stagger(P.prio);
 #endif
-    const int4 ent = P.spx[blockIdx.x];
+    const int4 ent = P.spx[BATCH ? item : (int)blockIdx.x];
     MHWsItem I;
     I.y = ent.x;  // may lie outside the cube when virtual
     I.x = ent.y;

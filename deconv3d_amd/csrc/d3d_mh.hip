@@ -52,6 +52,10 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.rev = 0;
     P.prio = c->mh_prio;
     P.props = nullptr;  // (run_part sets it for the parts whose colour launches are small)
+    P.batch = nullptr;  // (mh_sweeps_batch)
+    P.b_items = 0;
+    P.b_gcur = 0;
+    P.b_lay_g[0] = P.b_lay_g[1] = P.b_lay_g[2] = 0;
     P.z_part = c->z_part;
     P.z_E = c->z_E;
     P.z_db = 256;
@@ -443,6 +447,135 @@ int launch_mh_zb(d3d_ctx *c, d3d::MHArgs &P, unsigned n_items, uint32_t sweep, i
     P.z_E = c->z_E;
     if (c->ivar_is_uniform && c->uniform_fast_path) return launch_mh_zb_t<true>(c, P, n_items, sweep, layers);
     return launch_mh_zb_t<false>(c, P, n_items, sweep, layers);
+}
+
+// ---- batched chains: R contexts of one geometry, ONE launch per colour class -------------
+// (d3d_mh_sweeps_batch.)  The leader's arguments carry everything the chains share -- work
+// list, taps, pending-layer geometry --, MHArgs::batch what differs.
+template <bool UV>
+int launch_mh_batch_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+    constexpr int NS = 256;
+    const bool few = grid < (unsigned)c->flow_grid / 2;
+    auto go = [&](auto kern, int M) {
+        const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NS + 64), lds, c->stream, P, sweep);
+    };
+    const int nl = P.n_lay;
+    if (layers >= 2) {  // Dp <= 160: the staged G rows in two registers
+        if (few) {
+            if (nl == 0) go(d3d::k_mh_ws<NS, UV, 4, 2, 2, 0, false, false, true>, 2);
+            else if (nl == 1) go(d3d::k_mh_ws<NS, UV, 4, 2, 2, 1, false, false, true>, 2);
+            else go(d3d::k_mh_ws<NS, UV, 4, 2, 2, 2, false, false, true>, 2);
+        } else {
+            if (nl == 0) go(d3d::k_mh_ws<NS, UV, 2, 2, 2, 0, false, false, true>, 2);
+            else if (nl == 1) go(d3d::k_mh_ws<NS, UV, 2, 2, 2, 1, false, false, true>, 2);
+            else go(d3d::k_mh_ws<NS, UV, 2, 2, 2, 2, false, false, true>, 2);
+        }
+    } else {
+        if (nl == 0) go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 0, false, false, true>, 1);
+        else go(d3d::k_mh_ws<NS, UV, 4, 1, 4, 1, false, false, true>, 1);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t *accepted) {
+    d3d_ctx *L = cs[0];  // the leader: its stream, its work lists
+    const d3d_ctx::Part &pt = L->parts[0];
+    const int ncol = L->fh * L->fw;
+    int most = 0;
+    for (int col = 0; col < ncol; ++col) most = std::max(most, pt.off[col + 1] - pt.off[col]);
+    // two pending layers where the launch of all chains together fills the chip
+    const int layers = (L->Dp <= 160 && (long)most * R >= L->flow_grid / 2) ? 2 : 1;
+    const bool uv = L->ivar_is_uniform && L->uniform_fast_path;
+    // every chain on the leader's stream for the duration of the call
+    std::vector<hipStream_t> own(R);
+    for (int r = 0; r < R; ++r) {
+        HIP_TRY(hipStreamSynchronize(cs[r]->stream));
+        own[r] = cs[r]->stream;
+        cs[r]->stream = L->stream;
+    }
+    auto restore = [&]() {
+        for (int r = 0; r < R; ++r) cs[r]->stream = own[r];
+    };
+    int rc = 0;
+    d3d::MHChainArgs *dev = nullptr;
+    do {
+        std::vector<d3d::MHChainArgs> host(R);
+        for (int r = 0; r < R && !rc; ++r) {
+            d3d_ctx *c = cs[r];
+            if (!c->err_valid) rc = d3d_residual(c, nullptr);
+            if (!rc) rc = flush_pending(c);
+            if (rc) break;
+            if (hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream) != hipSuccess) rc = fail(D3D_ERR_HIP, "hipMemsetAsync");
+            d3d::MHChainArgs &B = host[r];
+            B.err = c->slot[D3D_SLOT_ERR];
+            B.ivar = c->slot[D3D_SLOT_IVAR];
+            B.ivar_uniform = c->ivar_uniform;
+            B.params = c->params;
+            B.prev = c->prev;
+            B.dlog = c->dlog;
+            B.accepted = c->accepted;
+            for (int b = 0; b < 4; ++b) B.gbuf[b] = c->gbuf[b];
+            for (int k = 0; k < 3; ++k) {
+                B.min_b[k] = c->min_b[k];
+                B.max_b[k] = c->max_b[k];
+                B.amp[k] = c->amp[k];
+            }
+            B.ra = c->ra;
+            B.seed = c->seed;
+            c->props_sweep = -1;
+        }
+        if (rc) break;
+        if (hipMalloc(&dev, R * sizeof(d3d::MHChainArgs)) != hipSuccess) { rc = fail(D3D_ERR_HIP, "hipMalloc"); break; }
+        if (hipMemcpy(dev, host.data(), R * sizeof(d3d::MHChainArgs), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(D3D_ERR_HIP, "hipMemcpy"); break; }
+        for (int s = first_sweep; s < first_sweep + n_sweeps && !rc; ++s) {
+            const uint32_t rs = (uint32_t)s + L->sweep_origin;
+            int ord = 0;
+            for (int col = 0; col < ncol && !rc; ++col) {
+                if (pt.real[col] <= 0) continue;
+                const int ka = ord++;
+                L->pend_part = 0;
+                d3d::MHArgs P;
+                fill_mh_args(L, P);
+                P.spx = L->spx + pt.off[col];
+                P.rev = (L->mh_zigzag && (ka & 1)) ? 1 : 0;
+                const int n_all = pt.off[col + 1] - pt.off[col];
+                P.write_back = (L->lay_n >= layers) ? 1 : 0;
+                const int g_cur = pend_free_buf(L);
+                P.batch = dev;
+                P.b_items = n_all;
+                P.b_gcur = g_cur;
+                for (int j = 0; j < 3; ++j) P.b_lay_g[j] = j < L->lay_n ? L->lay_g[j] : 0;
+                rc = uv ? launch_mh_batch_t<true>(L, P, (unsigned)n_all * R, rs, layers)
+                        : launch_mh_batch_t<false>(L, P, (unsigned)n_all * R, rs, layers);
+                if (rc) break;
+                const int cy = ((col / L->fw - L->gy0) % L->fh + L->fh) % L->fh;
+                const int cx = ((col % L->fw - L->gx0) % L->fw + L->fw) % L->fw;
+                for (int r = 0; r < R; ++r) {  // all chains keep their pending layers alike
+                    d3d_ctx *c = cs[r];
+                    if (P.write_back) c->lay_n = 0;
+                    pend_push(c, cy, cx, g_cur);
+                    c->pend_part = 0;
+                }
+            }
+            // lib/run.py:521-534, per chain
+            for (int r = 0; r < R && !rc; ++r)
+                if (cs[r]->refresh_every > 0 && s % cs[r]->refresh_every == 0)
+                    rc = forward_into(cs[r], cs[r]->slot[D3D_SLOT_ERR], true);
+        }
+        if (rc) break;
+        std::vector<unsigned long long> acc(R, 0);
+        for (int r = 0; r < R; ++r)
+            if (hipMemcpyAsync(&acc[r], cs[r]->accepted, sizeof(unsigned long long), hipMemcpyDeviceToHost, L->stream) != hipSuccess) rc = fail(D3D_ERR_HIP, "hipMemcpyAsync");
+        if (hipStreamSynchronize(L->stream) != hipSuccess) rc = fail(D3D_ERR_HIP, "hipStreamSynchronize");
+        if (!rc && accepted)
+            for (int r = 0; r < R; ++r) accepted[r] = (int64_t)acc[r];
+    } while (false);
+    (void)hipStreamSynchronize(L->stream);
+    if (dev) (void)hipFree(dev);
+    restore();
+    return rc;
 }
 
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,

@@ -250,6 +250,16 @@ int d3d_set_tile(d3d_ctx *ctx, int gy0, int gx0, int Wg, int oy0, int oy1, int o
  * disjoint, inside the owned rectangle) with phases[i] in [0,16).  nparts = 0
  * restores the single part.  Spaxels in no part are not updated. */
 int d3d_set_parts(d3d_ctx *ctx, int nparts, const int *rects, const int *phases);
+/* Several independent chains of ONE geometry in one launch per colour class (the ensemble of
+ * BASELINE config 5 on one device; lib/run.py has one chain per Run(), its sweep loop is
+ * lib/run.py:344-537).  ctxs[0..n_ctx): contexts on one device with the same shape, mask, FSF and
+ * LSF (data, variance values, bounds, parameters, seed may all differ), unpartitioned, at
+ * most 256 channels.  Every chain is the chain d3d_mh_sweeps would produce for its ctx alone
+ * (same kernels, same random streams); a small cube's colour launch, which alone leaves the chip
+ * idle, carries n_ctx times the windows for the same latency.  accepted[n_ctx] (may be NULL):
+ * accepted proposals per chain.  Samples are not streamed: read the state with
+ * d3d_get_params between calls. */
+int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int64_t *accepted);
 /* One phase of sweep `sweep`: every colour class of every part of that phase
  * (lib/run.py:367-519 restricted to them).  For callers that exchange the halos
  * themselves (loop-back, host-staged transports); d3d_mh_sweeps does whole sweeps

@@ -200,6 +200,58 @@ def test_concurrent_chains_on_one_gpu_are_the_chains_they_would_be_alone():
             e.close()
 
 
+@pytest.mark.parametrize("name,n_chains", [("c1", 5), ("tile_a", 16), ("odd_depth", 3)])
+def test_batched_chains_are_the_chains_they_would_be_alone(name, n_chains):
+    """d3d_mh_sweeps_batch (ensemble.sweep_chains_batched): R contexts of one geometry -- other
+    data, bounds, start and seed each -- in ONE launch per colour class: parameters, carried
+    residual, log-ratio map and accepted count of every chain equal those of its context run
+    alone, bit for bit (whatever pending-layer depth the joint launch takes), across two calls
+    and a periodic residual rebuild; contexts that do not share mask or taps are refused."""
+    from deconv3d_amd import ensemble
+    from tests.cases import make_case
+    case = make_case(name)     # (tile_a x 16: the joint launch fills the chip -- two pending layers)
+    D, H, W = case["D"], case["H"], case["W"]
+    rng = np.random.default_rng(17)
+
+    def make(r):
+        eng = _lib.Engine((D, H, W), case["fsf"].shape)
+        eng.set_taps(case["fsf"], case["lsf"])
+        data = case["data"] * (1.0 + 0.1 * r) + 0.01 * r
+        eng.set_data(data, case["var"] * (1.0 + 0.05 * r), mask=case["mask"])
+        init = case["init"].copy()
+        init[..., 1] = np.clip(init[..., 1] + 0.3 * r, 0, D - 1)
+        eng.set_params(init)
+        max_b = case["max_b"] * np.array([1.0 + 0.1 * r, 1.0, 1.0])
+        eng.mh_config(case["min_b"], max_b, 0.1, 40.0 + r, seed=100 + r, refresh_every=4)
+        return eng
+
+    alone = []
+    for r in range(n_chains):
+        with make(r) as eng:
+            acc = eng.mh_sweeps(3, 1) + eng.mh_sweeps(4, 4)
+            alone.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), acc))
+    engs = [make(r) for r in range(n_chains)]
+    try:
+        a1 = ensemble.sweep_chains_batched(engs, 3, 1)
+        a2 = ensemble.sweep_chains_batched(engs, 4, 4)
+        for r, eng in enumerate(engs):
+            np.testing.assert_array_equal(eng.get_params(), alone[r][0])
+            np.testing.assert_array_equal(eng.download_slot(_lib.SLOT_ERR), alone[r][1])
+            np.testing.assert_array_equal(eng.get_dlog(), alone[r][2])
+            assert a1[r] + a2[r] == alone[r][3]
+        assert not np.array_equal(alone[0][0], alone[1][0])
+        # a chain goes on alone afterwards
+        engs[1].mh_sweeps(1, 8)
+        other_mask = case["mask"].copy()
+        other_mask[0, 0] = 1 - other_mask[0, 0]
+        engs[0].set_data(case["data"], case["var"], mask=other_mask)
+        with pytest.raises(ValueError, match="mask"):
+            ensemble.sweep_chains_batched(engs, 1, 9)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_run_is_reproducible_and_seed_sensitive():
     inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
     a = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)

@@ -39,3 +39,15 @@ for R in (1, 2, 4, 8, 16):
     dt = time.perf_counter() - t0
     print("%s: %2d chains, one host thread interleaving sweeps: %.3f ms per sweep of all chains, %.2f M updates/s in total" % (wl, R, dt * 1e3 / nsw, R * nsw * H * W / dt / 1e6), flush=True)
     for e in engs: e.close()
+
+# batched: R chains of one geometry in ONE launch per colour class (d3d_mh_sweeps_batch)
+for R in (1, 4, 8, 16, 32, 64):
+    if R * D * H * W * 8 * 10 > 40e9:
+        break
+    engs = [make(100 + r) for r in range(R)]
+    _lib.mh_sweeps_batch(engs, 10, 11)
+    t0 = time.perf_counter()
+    _lib.mh_sweeps_batch(engs, nsw, 21)
+    dt = time.perf_counter() - t0
+    print("%s: %2d chains batched into one launch per colour class: %.3f ms per sweep of all chains, %.2f M updates/s in total" % (wl, R, dt * 1e3 / nsw, R * nsw * H * W / dt / 1e6), flush=True)
+    for e in engs: e.close()
