@@ -25,6 +25,7 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
                           1/variance (369 MB) exceed the 256 MB Infinity Cache
   roofline_deep        -- the sweep on a 200x200x1024 cube: the z-blocked form of the kernel
                           (one workgroup per window and 256-channel block + a decision launch)
+  chains_batched       -- config 2's cube as 16 independent chains in one launch per colour class
   roofline_conv        -- the separable LSF (x) FSF convolution of one cube
   cpu_baseline         -- the oracle's memory-sane numpy update loop on the host cores
   cpu_baseline_conv    -- the oracle's LSF (x) FSF convolution of one cube on the host
@@ -382,6 +383,48 @@ def mh_cube_leg(args, local_rank, fs, shape, label, traffic_key):
                 "value": round(steps * H * W / (ms * 1e-3), 1), "unit_value": "spaxel-updates/s"}
 
 
+def batched_chains_leg(args, local_rank, chains=16, workload="c2_64x64x64"):
+    """BASELINE config 2's cube as an ENSEMBLE on one GPU: `chains` independent chains (other
+    seeds) in ONE launch per colour class (d3d_mh_sweeps_batch).  A single chain of that cube
+    is a latency chain of 121 small launches (49 windows for 1024 workgroup slots); the joint
+    launch carries 16 times the windows for about the same latency.  Aggregate rate; every chain
+    is bit-identical to the chain run alone (tests/test_gpu_run.py)."""
+    from deconv3d_amd import _lib
+    D, H, W, fs = WORKLOADS[workload]
+    fsf, lsf = build_taps(D, fs)
+    engs = []
+    try:
+        for r in range(chains):
+            eng = _lib.Engine((D, H, W), fsf.shape, device=local_rank)
+            engs.append(eng)
+            eng.set_taps(fsf, lsf)
+            data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 4000 + r)
+            eng.set_data(data, var, mask=None)
+            eng.set_params(init)
+            eng.mh_config(min_b, max_b, 0.1, float(max_b[0] ** 2), seed=4000 + r, refresh_every=0)
+        steps = max(20, min(10 * args.steps, 200))
+        single = engs[0]
+        single.residual(fetch=False)
+        single.mh_sweeps(5, 1)
+        single.sync()
+        t0 = time.perf_counter()
+        single.mh_sweeps(steps, 6)
+        one = steps * H * W / (time.perf_counter() - t0)
+        single.set_params(init)
+        _lib.mh_sweeps_batch(engs, 5, 1)
+        t0 = time.perf_counter()
+        acc = _lib.mh_sweeps_batch(engs, steps, 6)
+        dt = time.perf_counter() - t0
+        return {"workload": workload, "chains": chains, "value": round(chains * steps * H * W / dt, 1),
+                "unit": "spaxel-updates/s", "ms_per_sweep_of_all_chains": round(dt * 1e3 / steps, 4),
+                "one_chain_alone": round(one, 1), "acceptance": round(sum(acc) / (chains * steps * H * W), 3),
+                "note": "extra: %d independent chains of one geometry in one launch per colour class "
+                        "(wall clock around the call); not `value`" % chains}
+    finally:
+        for e in engs:
+            e.close()
+
+
 def conv_beyond_mall_leg(args, local_rank, fs):
     """The one-pass convolution on a 600x600x128 cube: 369 MB in + 369 MB out, beyond the
     256 MB Infinity Cache that can hold most of the headline cube's 92 + 92 MB."""
@@ -671,6 +714,9 @@ def main():
             out["roofline_deep"] = deep_leg(args, local_rank, fs)
         if not args.no_conv_beyond_mall:
             out["roofline_conv_beyond_mall"] = conv_beyond_mall_leg(args, local_rank, fs)
+            # (skipped with it in the profile round: the same kernel names as the headline leg's
+            # small-launch variants would mix into the counter averages)
+            out["chains_batched"] = batched_chains_leg(args, local_rank)
     if rank == 0 and not args.no_extras:
         # the reference's default variance (Run(variance=None): one constant,
         # lib/run.py:171-178): the MH kernel does not read SLOT_IVAR at all
