@@ -337,7 +337,7 @@ def beyond_mall_leg(args, local_rank, fs):
     the 184 MB working set of the headline cube partly is.  Priced like `roofline`."""
     return mh_cube_leg(args, local_rank, fs, (256, 300, 300),
                        "k_mh_ws, 300x300x256 cube (working set 369 MB > 256 MB MALL)",
-                       ("k_mh_ws<256, false, 2, 2, 4,", "true, false>"))
+                       ("k_mh_ws<256, false, 2, 2, 4,", "true, false, false>"))
 
 
 def deep_leg(args, local_rank, fs):
@@ -347,7 +347,7 @@ def deep_leg(args, local_rank, fs):
     PAIR of launches of one colour class."""
     return mh_cube_leg(args, local_rank, fs, (1024, 200, 200),
                        "k_mh_ws<..., ZBK> + k_mh_zdecide, 200x200x1024 cube (z-blocks of 256 channels)",
-                       ("k_mh_ws<256, false, 2, 2, 4,", "true, true>"))
+                       ("k_mh_ws<256, false, 2, 2, 4,", "true, true, false>"))
 
 
 def mh_cube_leg(args, local_rank, fs, shape, label, traffic_key):
@@ -611,7 +611,7 @@ def main():
     roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload, "false, false>"),
+                "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload, "false, false, false>"),
                 "bytes_per_launch": bytes_per_sweep // ncol,
                 "avg_launch_us": round(avg_launch_us, 2), "launches": launches,
                 # `achieved` prices the 24 B per window voxel of SURVEY 8(d) (read residual,
@@ -738,7 +738,7 @@ def main():
                 "bytes_per_launch": bytes_per_sweep * 2 // 3 // ncol,
                 "avg_launch_us": round(u_us, 2), "achieved": round(u_gbs, 1),
                 "frac": round(u_gbs / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("k_mh_ws<256, true, 4, 2, 2,", args.workload, "false, false>"),
+                "traffic": measured_traffic("k_mh_ws<256, true, 4, 2, 2,", args.workload, "false, false, false>"),
                 "note": "extra: reference default variance=None (one constant); not `value`"}
 
     if rank == 0 and not args.no_extras:
