@@ -121,7 +121,8 @@ def load():
     int_p = C.POINTER(C.c_int)
     lib.d3d_set_parts.argtypes = [ctx_p, C.c_int, int_p, int_p]
     lib.d3d_mh_phase.argtypes = [ctx_p, C.c_int, C.c_int]
-    lib.d3d_mh_sweeps_batch.argtypes = [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+    lib.d3d_mh_sweeps_batch.argtypes = [C.POINTER(ctx_p), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
     lib.d3d_mh_accepted.argtypes = [ctx_p, C.POINTER(C.c_int64), C.c_int]
     lib.d3d_flush.argtypes = [ctx_p]
     lib.d3d_halo_plan.argtypes = [ctx_p, C.c_int, C.c_int, int_p]
@@ -168,14 +169,35 @@ def comm_unique_id():
     return buf.raw
 
 
-def mh_sweeps_batch(engines, n_sweeps, first_sweep=1):
+def mh_sweeps_batch(engines, n_sweeps, first_sweep=1, keep_one_in=1, chains=None, dlogs=None):
     """d3d_mh_sweeps_batch: the chains of several Engines of one geometry, one launch per colour
-    class for all of them.  Returns the accepted counts, one per engine."""
+    class for all of them.  chains / dlogs: per-engine host arrays as Engine.mh_sweeps takes
+    them (or None; a None entry skips that engine).  Returns the accepted counts."""
     lib = load()
     n = len(engines)
+    last = (first_sweep + n_sweeps - 1) // keep_one_in
+
+    def pointers(arrs, tail):
+        if arrs is None:
+            return None
+        if len(arrs) != n:
+            raise ValueError("one array (or None) per engine")
+        out = (C.c_void_p * n)()
+        for i, (a, e) in enumerate(zip(arrs, engines)):
+            if a is None:
+                continue
+            H, W = e.shape[1:]
+            if (a.dtype != np.float64 or not a.flags.c_contiguous or a.shape[1:] != (H, W) + tail
+                    or a.shape[0] <= last):
+                raise ValueError("chain / dlog array %d: float64, C-contiguous, (>%d, %d, %d%s)"
+                                 % (i, last, H, W, ", 3" if tail else ""))
+            out[i] = a.ctypes.data
+        return out
+
     arr = (C.c_void_p * n)(*[e._ctx.value for e in engines])
     acc = (C.c_int64 * n)()
-    _check(lib.d3d_mh_sweeps_batch(arr, n, int(n_sweeps), int(first_sweep), acc))
+    _check(lib.d3d_mh_sweeps_batch(arr, n, int(n_sweeps), int(first_sweep), int(keep_one_in),
+                                   pointers(chains, (3,)), pointers(dlogs, ()), acc))
     return [int(v) for v in acc]
 
 

@@ -1477,9 +1477,11 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     return D3D_OK;
 }
 
-int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int64_t *accepted) {
+int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int keep_one_in,
+                        double **chain_out, double **dlog_out, int64_t *accepted) {
     NEED(ctxs && n_ctx >= 1, D3D_ERR_INVALID, "no contexts");
     NEED(n_sweeps >= 0 && first_sweep >= 0, D3D_ERR_INVALID, "negative sweep count/index");
+    NEED(keep_one_in > 0, D3D_ERR_INVALID, "keep_one_in= MUST be a positive integer");
     d3d_ctx *L = ctxs[0];
     for (int r = 0; r < n_ctx; ++r) {
         d3d_ctx *c = ctxs[r];
@@ -1503,7 +1505,33 @@ int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep
              "ctx %d: another walk order or sweep origin than ctx 0", r);
     }
     HIP_TRY(hipSetDevice(L->device));
-    return mh_sweeps_batch(ctxs, n_ctx, n_sweeps, first_sweep, accepted);
+    // saved sweeps (lib/run.py:353, 430-432, 449-451): every chain streams its samples as
+    // d3d_mh_sweeps does -- device snapshot on the common stream, copy stream, pinned ring
+    const bool saving = chain_out || dlog_out;
+    std::vector<SnapQueue> snaps(n_ctx);
+    if (saving)
+        for (int r = 0; r < n_ctx; ++r)
+            if (int rc = snap_setup(ctxs[r])) return rc;
+    auto co = [&](int r) { return chain_out ? chain_out[r] : nullptr; };
+    auto lo = [&](int r) { return dlog_out ? dlog_out[r] : nullptr; };
+    std::function<int(int)> after;
+    std::function<int()> drain;
+    if (saving) {
+        after = [&](int s) {
+            if (s % keep_one_in) return 0;
+            for (int r = 0; r < n_ctx; ++r)
+                if (co(r) || lo(r))
+                    if (int rc = snap_push(ctxs[r], snaps[r], s / keep_one_in, co(r), lo(r))) return rc;
+            return 0;
+        };
+        drain = [&]() {
+            for (int r = 0; r < n_ctx; ++r)
+                while (snaps[r].count > 0)
+                    if (int rc = snap_drain_one(ctxs[r], snaps[r], co(r), lo(r))) return rc;
+            return 0;
+        };
+    }
+    return mh_sweeps_batch(ctxs, n_ctx, n_sweeps, first_sweep, accepted, after, drain);
 }
 
 int d3d_mh_phase(d3d_ctx *c, int phase, int sweep) {

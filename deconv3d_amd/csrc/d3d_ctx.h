@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <functional>
 #include <vector>
 
 #include "../../include/deconv3d_hip.h"
@@ -272,7 +273,8 @@ void pend_push(d3d_ctx *c, int cy, int cx, int g);
 void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P);
 int launch_mh(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep);
 int launch_mh_zb(d3d_ctx *c, d3d::MHArgs &P, unsigned n_items, uint32_t sweep, int layers);
-int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t *accepted);
+int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t *accepted,
+                    const std::function<int(int)> &after_sweep, const std::function<int()> &drain);
 int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers,
                     bool wide);
 int flush_pending(d3d_ctx *c);

@@ -479,7 +479,8 @@ int launch_mh_batch_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t 
     return 0;
 }
 
-int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t *accepted) {
+int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t *accepted,
+                    const std::function<int(int)> &after_sweep, const std::function<int()> &drain) {
     d3d_ctx *L = cs[0];  // the leader: its stream, its work lists
     const d3d_ctx::Part &pt = L->parts[0];
     const int ncol = L->fh * L->fw;
@@ -559,11 +560,14 @@ int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t 
                     c->pend_part = 0;
                 }
             }
+            if (!rc && after_sweep) rc = after_sweep(s);  // (saved sweeps: snapshots of every chain)
             // lib/run.py:521-534, per chain
             for (int r = 0; r < R && !rc; ++r)
                 if (cs[r]->refresh_every > 0 && s % cs[r]->refresh_every == 0)
                     rc = forward_into(cs[r], cs[r]->slot[D3D_SLOT_ERR], true);
         }
+        if (rc) break;
+        if (drain) rc = drain();
         if (rc) break;
         std::vector<unsigned long long> acc(R, 0);
         for (int r = 0; r < R; ++r)

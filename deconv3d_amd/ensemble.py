@@ -17,14 +17,15 @@ import threading
 from . import _lib
 
 
-def sweep_chains_batched(engines, n_sweeps, first_sweep=1):
+def sweep_chains_batched(engines, n_sweeps, first_sweep=1, keep_one_in=1, chains=None, dlogs=None):
     """The chains of several engines of ONE geometry (same shape, mask, FSF, LSF; data,
     variance values, bounds, start and seed may differ) in one launch per colour class
     (d3d_mh_sweeps_batch): a small cube's launch carries len(engines) times the windows
     for the same latency, beyond what concurrent streams give (config 2: see
     profiles/r03_replicas.txt).  Cubes up to 256 channels, unpartitioned.  Returns the
-    accepted counts; samples are not streamed -- read engine.get_params() between calls."""
-    return _lib.mh_sweeps_batch(list(engines), n_sweeps, first_sweep)
+    accepted counts; chains / dlogs: per-engine host arrays (or None) that receive the saved
+    sweeps exactly as Engine.mh_sweeps fills them."""
+    return _lib.mh_sweeps_batch(list(engines), n_sweeps, first_sweep, keep_one_in, chains, dlogs)
 
 
 def sweep_chains(engines, n_sweeps, first_sweep=1, keep_one_in=1, chains=None, dlogs=None):

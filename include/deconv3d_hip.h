@@ -256,10 +256,11 @@ int d3d_set_parts(d3d_ctx *ctx, int nparts, const int *rects, const int *phases)
  * LSF (data, variance values, bounds, parameters, seed may all differ), unpartitioned, at
  * most 256 channels.  Every chain is the chain d3d_mh_sweeps would produce for its ctx alone
  * (same kernels, same random streams); a small cube's colour launch, which alone leaves the chip
- * idle, carries n_ctx times the windows for the same latency.  accepted[n_ctx] (may be NULL):
- * accepted proposals per chain.  Samples are not streamed: read the state with
- * d3d_get_params between calls. */
-int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int64_t *accepted);
+ * idle, carries n_ctx times the windows for the same latency.  keep_one_in, chain_out[n_ctx],
+ * dlog_out[n_ctx] (arrays of per-chain pointers, or NULL; a NULL entry skips that chain): as in
+ * d3d_mh_sweeps, per chain.  accepted[n_ctx] (may be NULL): accepted proposals per chain. */
+int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep, int keep_one_in,
+                        double **chain_out, double **dlog_out, int64_t *accepted);
 /* One phase of sweep `sweep`: every colour class of every part of that phase
  * (lib/run.py:367-519 restricted to them).  For callers that exchange the halos
  * themselves (loop-back, host-staged transports); d3d_mh_sweeps does whole sweeps

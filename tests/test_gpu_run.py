@@ -228,17 +228,26 @@ def test_batched_chains_are_the_chains_they_would_be_alone(name, n_chains):
     alone = []
     for r in range(n_chains):
         with make(r) as eng:
-            acc = eng.mh_sweeps(3, 1) + eng.mh_sweeps(4, 4)
-            alone.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), acc))
+            chain = np.full((4, H, W, 3), np.nan)
+            dlog = np.full((4, H, W), np.nan)
+            acc = eng.mh_sweeps(3, 1, 2, chain, dlog) + eng.mh_sweeps(4, 4, 2, chain, dlog)
+            alone.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), acc, chain, dlog))
     engs = [make(r) for r in range(n_chains)]
     try:
-        a1 = ensemble.sweep_chains_batched(engs, 3, 1)
-        a2 = ensemble.sweep_chains_batched(engs, 4, 4)
+        # (saved sweeps streamed per chain, every second sweep; the last engine opts out)
+        chains = [np.full((4, H, W, 3), np.nan) for _ in engs[:-1]] + [None]
+        dlogs = [np.full((4, H, W), np.nan) for _ in engs[:-1]] + [None]
+        a1 = ensemble.sweep_chains_batched(engs, 3, 1, 2, chains, dlogs)
+        a2 = ensemble.sweep_chains_batched(engs, 4, 4, 2, chains, dlogs)
         for r, eng in enumerate(engs):
             np.testing.assert_array_equal(eng.get_params(), alone[r][0])
             np.testing.assert_array_equal(eng.download_slot(_lib.SLOT_ERR), alone[r][1])
             np.testing.assert_array_equal(eng.get_dlog(), alone[r][2])
             assert a1[r] + a2[r] == alone[r][3]
+            if chains[r] is not None:
+                np.testing.assert_array_equal(chains[r][1:], alone[r][4][1:])     # slots 1..3: sweeps 2, 4, 6
+                np.testing.assert_array_equal(dlogs[r][1:], alone[r][5][1:])
+                assert np.isnan(chains[r][0]).all()
         assert not np.array_equal(alone[0][0], alone[1][0])
         # a chain goes on alone afterwards
         engs[1].mh_sweeps(1, 8)
