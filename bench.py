@@ -324,6 +324,26 @@ def measured_traffic(kernel_prefix, workload, kernel_suffix=""):
     return best
 
 
+def fp64_rates(entry, flops, ms, shape=None, instr_per_pair_step=None, fs=11):
+    """The convolution's fp64 figures, labelled for what they are.  `fp64_algorithmic_*`:
+    2 (fh fw + LSF taps) flops per voxel -- the arithmetic of the reference's dense stencil
+    (lib/run.py:1027-1029), NOT an issue rate: k_conv_rows folds both mirror symmetries of
+    the FSF.  `fp64_issued_*`: the fp64 instructions the kernel actually issues per lane
+    (csrc/d3d_conv.h: `instr_per_pair_step` per z-pair and march step, halo steps of a strip
+    included), against the vector unit's issue peak (78.6 TFLOP/s / 2 flops per FMA)."""
+    entry["fp64_algorithmic_tflops"] = round(flops / (ms * 1e-3) / 1e12, 2)
+    entry["fp64_algorithmic_frac"] = round(flops / (ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)
+    if shape is not None and instr_per_pair_step is not None:
+        D, H, W = shape
+        ngx = (W + 14) // 15                      # launch_conv_rows_t: 15 columns per workgroup,
+        ngy = min(max(1, 256 // ngx), H)          # one workgroup per CU, one round
+        hy = (H + ngy - 1) // ngy
+        steps = (H + hy - 1) // hy * (hy + fs - 1)
+        issued = instr_per_pair_step / 2.0 * D * W * steps
+        entry["fp64_issued_tinstr_per_s"] = round(issued / (ms * 1e-3) / 1e12, 2)
+        entry["fp64_issue_frac"] = round(issued / (ms * 1e-3) / 1e12 / (FP64_VEC_PEAK_TF / 2.0), 4)
+
+
 def traffic_rates(entry, us):
     """traffic_gbs / traffic_frac of a roofline entry whose `traffic` is a byte count."""
     if isinstance(entry.get("traffic"), int) and entry["traffic"] > 0:
@@ -392,7 +412,7 @@ def batched_chains_leg(args, local_rank, chains=16, workload="c2_64x64x64"):
     from deconv3d_amd import _lib
     D, H, W, fs = WORKLOADS[workload]
     fsf, lsf = build_taps(D, fs)
-    engs = []
+    engs, inits = [], []
     try:
         for r in range(chains):
             eng = _lib.Engine((D, H, W), fsf.shape, device=local_rank)
@@ -401,6 +421,7 @@ def batched_chains_leg(args, local_rank, chains=16, workload="c2_64x64x64"):
             data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 4000 + r)
             eng.set_data(data, var, mask=None)
             eng.set_params(init)
+            inits.append(init)
             eng.mh_config(min_b, max_b, 0.1, float(max_b[0] ** 2), seed=4000 + r, refresh_every=0)
         steps = max(20, min(10 * args.steps, 200))
         single = engs[0]
@@ -410,7 +431,7 @@ def batched_chains_leg(args, local_rank, chains=16, workload="c2_64x64x64"):
         t0 = time.perf_counter()
         single.mh_sweeps(steps, 6)
         one = steps * H * W / (time.perf_counter() - t0)
-        single.set_params(init)
+        single.set_params(inits[0])
         _lib.mh_sweeps_batch(engs, 5, 1)
         t0 = time.perf_counter()
         acc = _lib.mh_sweeps_batch(engs, steps, 6)
@@ -446,11 +467,14 @@ def conv_beyond_mall_leg(args, local_rank, fs):
     gbs = nbytes / (ms * 1e-3) / 1e9
     ntaps = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
     flops = 2.0 * (fsf.size + ntaps) * D * H * W
-    return {"kernel": "k_conv_rows, 600x600x128 cube (369 MB in + 369 MB out > 256 MB MALL)",
-            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": nbytes,
-            "ms_per_conv": round(ms, 4), "fp64_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-            "fp64_frac": round(flops / (ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)}
+    out = {"kernel": "k_conv_rows, 600x600x128 cube (369 MB in + 369 MB out > 256 MB MALL)",
+           "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "traffic": measured_traffic("k_conv_rows<11, 15, true, true, false, 1,", "conv_600x600x128"),
+           "algorithmic_bytes": nbytes, "ms_per_conv": round(ms, 4)}
+    traffic_rates(out, ms * 1e3)
+    fp64_rates(out, flops, ms, (D, H, W), 136, fs)
+    return out
 
 
 def main():
@@ -632,14 +656,14 @@ def main():
     ntaps_lsf = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
     conv_flops = 2.0 * (fh * fw + ntaps_lsf) * D * H * W
 
-    def conv_entry(ms, kernel, traffic_key):
+    def conv_entry(ms, kernel, traffic_key, flops=conv_flops, instr=None):
         gbs = conv_bytes / (ms * 1e-3) / 1e9
-        return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+        e = {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic(traffic_key, args.workload),
-                "ms_per_conv": round(ms, 4),
-                "fp64_tflops": round(conv_flops / (ms * 1e-3) / 1e12, 2),
-                "fp64_frac": round(conv_flops / (ms * 1e-3) / 1e12 / FP64_VEC_PEAK_TF, 4)}
+                "ms_per_conv": round(ms, 4)}
+        fp64_rates(e, flops, ms, (D, H, W) if instr else None, instr, fh)
+        return e
 
     eng.stage_upload(data)
     eng.stage_convolve()                                          # warm
@@ -654,8 +678,12 @@ def main():
     for _ in range(args.conv_iters):
         eng.convolve_slots(_lib.SLOT_DATA, _lib.SLOT_SIM)
     slots_ms = eng.timer_stop() / max(args.conv_iters, 1)
+    # (136 / 68 fp64 instructions per z-pair and march step: radial / outer-product FSF + 17-tap
+    # LSF epilogue at 128 channels, csrc/d3d_conv.h; other shapes: no issued figure)
+    at128 = D == 128 and fh == 11
     roofline_conv = conv_entry(slots_ms, "k_conv_rows (LSF x FSF in one pass, slot layout)",
-                               "k_conv_rows<11, 15, true, true, false, 1,")
+                               "k_conv_rows<11, 15, true, true, false, 1,",
+                               instr=136 if at128 else None)
     roofline_conv["algorithmic_bytes"] = conv_bytes
     roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
                                           "k_spatial_z")
@@ -757,10 +785,8 @@ def main():
             g_ms = eng.timer_stop() / max(args.conv_iters, 1)
             out["roofline_conv_gaussian"] = conv_entry(
                 g_ms, "k_conv_rows, outer-product form (Gaussian 11x11 FSF; LSF in the same pass)",
-                "k_conv_rows<11, 15, true, true, false, 2,")
-            out["roofline_conv_gaussian"]["fp64_tflops"] = round(
-                2.0 * (fh + fw + ntaps_lsf) * D * H * W / (g_ms * 1e-3) / 1e12, 2)
-            out["roofline_conv_gaussian"].pop("fp64_frac", None)
+                "k_conv_rows<11, 15, true, true, false, 2,",
+                flops=2.0 * (fh + fw + ntaps_lsf) * D * H * W, instr=68 if at128 else None)
 
     if rank == 0 and not args.no_cpu:
         cores = len(os.sched_getaffinity(0))

@@ -1263,7 +1263,9 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
     const bool deferred =
         c->mh_defer &&
         (!partitioned || (c->mh_defer == 1 && (c->Dp <= d3d::MH_WS_MAX_DP || c->mh_zb)));
-    if (c->lay_n && (c->pend_part != pi || !deferred))
+    // (more layers pending than this part's kernels take: a batched launch that filled the chip
+    // left two, the context alone keeps one)
+    if (c->lay_n && (c->pend_part != pi || !deferred || c->lay_n > pt.layers))
         if (int rc = flush_pending(c)) return rc;
 #ifdef D3D_EXPERIMENTS
     if (deferred && pt.chain) return launch_mh_chain(c, pi, sweep, 1);  // all colours in one launch
@@ -1339,6 +1341,18 @@ int run_phase(d3d_ctx *c, int phase, uint32_t sweep) {
 }
 
 int halo_exchange(d3d_ctx *c, int plan);
+// option halo_timing: the oldest event pair in flight, reduced into halo_ms / halo_count
+int halo_drain_one(d3d_ctx *c) {
+    const size_t at = c->halo_ev_head;
+    float f = 0.f;
+    HIP_TRY(hipEventSynchronize(c->halo_ev[2 * at + 1]));
+    HIP_TRY(hipEventElapsedTime(&f, c->halo_ev[2 * at], c->halo_ev[2 * at + 1]));
+    c->halo_ms += (double)f;
+    ++c->halo_count;
+    c->halo_ev_head = (at + 1) % d3d_ctx::HALO_RING;
+    --c->halo_ev_used;
+    return 0;
+}
 bool plan_has_entries(const d3d_ctx *c, int plan) {
     return plan >= 0 && plan < (int)c->plans.size() && !c->plans[plan].empty();
 }
@@ -1373,6 +1387,8 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     }
     HIP_TRY(hipMemsetAsync(c->accepted, 0, sizeof(unsigned long long), c->stream));
     c->props_sweep = -1;  // a proposal table never outlives the call it was made in
+    c->halo_ev_used = 0;  // (pairs a failed call left behind are dropped)
+    c->halo_ev_head = 0;
     SnapQueue snaps;
     if (chain_out || dlog_out)
         if (int rc = snap_setup(c)) return rc;
@@ -1416,16 +1432,19 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
                 if (plan_has_entries(c, ph)) {
                     hipEvent_t ev[2] = {nullptr, nullptr};
                     if (c->halo_timing) {
-                        if (c->halo_ev_used + 2 > c->halo_ev.size()) {
-                            for (int k = 0; k < 2; ++k) {
-                                hipEvent_t e;
-                                HIP_TRY(hipEventCreate(&e));
-                                c->halo_ev.push_back(e);
-                            }
+                        // a bounded ring of event pairs: a long call (50 000 sweeps x 2-4
+                        // phases) reduces the oldest pair when the ring is full
+                        if (c->halo_ev_used == d3d_ctx::HALO_RING)
+                            if (int rc2 = halo_drain_one(c)) return rc2;
+                        const size_t at = (c->halo_ev_head + c->halo_ev_used) % d3d_ctx::HALO_RING;
+                        while (c->halo_ev.size() < 2 * (at + 1)) {
+                            hipEvent_t e;
+                            HIP_TRY(hipEventCreate(&e));
+                            c->halo_ev.push_back(e);
                         }
-                        ev[0] = c->halo_ev[c->halo_ev_used];
-                        ev[1] = c->halo_ev[c->halo_ev_used + 1];
-                        c->halo_ev_used += 2;
+                        ev[0] = c->halo_ev[2 * at];
+                        ev[1] = c->halo_ev[2 * at + 1];
+                        ++c->halo_ev_used;
                         HIP_TRY(hipEventRecord(ev[0], c->stream));
                     }
                     rc = halo_exchange(c, ph);
@@ -1461,13 +1480,8 @@ int d3d_mh_sweeps(d3d_ctx *c, int n_sweeps, int first_sweep, int keep_one_in, do
     while (snaps.count > 0)
         if (int rc = snap_drain_one(c, snaps, chain_out, dlog_out)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    for (size_t i = 0; i + 1 < c->halo_ev_used; i += 2) {  // option halo_timing
-        float f = 0.f;
-        HIP_TRY(hipEventElapsedTime(&f, c->halo_ev[i], c->halo_ev[i + 1]));
-        c->halo_ms += (double)f;
-        ++c->halo_count;
-    }
-    c->halo_ev_used = 0;
+    while (c->halo_ev_used > 0)  // option halo_timing
+        if (int rc = halo_drain_one(c)) return rc;
     if (accepted) *accepted = (int64_t)acc;
     c->chain_used = false;
     NEED(!flow_err, D3D_ERR_HIP,
@@ -1503,6 +1517,11 @@ int d3d_mh_sweeps_batch(d3d_ctx **ctxs, int n_ctx, int n_sweeps, int first_sweep
              D3D_ERR_INVALID, "ctx %d: uniform and per-voxel variances cannot share a launch", r);
         NEED(c->mh_zigzag == L->mh_zigzag && c->sweep_origin == L->sweep_origin, D3D_ERR_INVALID,
              "ctx %d: another walk order or sweep origin than ctx 0", r);
+        // (the chains share the leader's pending-layer state, and a from-scratch residual
+        // clears a chain's own: they must all be rebuilt at the same sweeps)
+        NEED(c->refresh_every == L->refresh_every, D3D_ERR_INVALID,
+             "ctx %d: refresh_every %d differs from ctx 0's %d (batched chains rebuild their residuals together)",
+             r, c->refresh_every, L->refresh_every);
     }
     HIP_TRY(hipSetDevice(L->device));
     // saved sweeps (lib/run.py:353, 430-432, 449-451): every chain streams its samples as

@@ -121,8 +121,9 @@ struct d3d_ctx {
     int comm_rank = -1, comm_size = 0;
     // option halo_timing = 1: HIP events around every halo exchange of d3d_mh_sweeps
     int halo_timing = 0;
-    std::vector<hipEvent_t> halo_ev;   // pairs (start, stop), recorded on the ctx stream
-    size_t halo_ev_used = 0;
+    static constexpr size_t HALO_RING = 64;  // event pairs in flight at most
+    std::vector<hipEvent_t> halo_ev;   // ring of pairs (start, stop), recorded on the ctx stream
+    size_t halo_ev_used = 0, halo_ev_head = 0;  // pairs in flight, oldest pair
     double halo_ms = 0.0;              // summed at the end of each d3d_mh_sweeps call
     long halo_count = 0;
     std::vector<uint8_t> h_mask;

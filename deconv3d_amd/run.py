@@ -214,6 +214,7 @@ class Run:
                     "%s_likelihoods.npy" % chain_file, mode="w+", dtype=np.float64,
                     shape=chain_shape[:3])
                 likelihoods[0] = np.nan
+                self._likelihoods_map = likelihoods
             else:
                 self.chain = np.full(chain_shape, np.nan)
                 likelihoods = np.full(chain_shape[:3], np.nan)
@@ -364,7 +365,8 @@ class Run:
     def _write_checkpoint(self, name, iteration, accepted_count):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
         lib/run.py:790-797), `<name>_chain.npy` (slots written so far) and
-        `<name>_state.npz` (iteration, seed, accepted count: `resume_state=`).
+        `<name>_state.npz` (iteration, seed, accepted count, `n_valid` = chain slots
+        written so far: `resume_state=`).
         A memory-mapped chain (`chain_file=`) is flushed where it lives instead of
         copied: the checkpoint then names its files, and `chain_file == checkpoint`
         cannot rewrite the file under the open mapping."""
@@ -373,12 +375,15 @@ class Run:
                  keep_one_in=self.keep_one_in,
                  total_accepted=accepted_count + self._acc_base,
                  total_iterations=iteration + self._it_base,
+                 n_valid=(iteration - 1) // self.keep_one_in + 1,
                  chain_file="" if self._chain_file is None else str(self._chain_file))
         np.save("%s_parameters.npy" % name, self._host_chain.params if self._host_model
                 else self.engine.get_params())
         n_valid = (iteration - 1) // self.keep_one_in + 1
         if self._chain_file is not None:
+            # slots past n_valid (recorded in the state file) are not written yet
             self.chain.flush()
+            self._likelihoods_map.flush()
         else:
             np.save("%s_chain.npy" % name, self.chain[:n_valid])
         self.logger.info("checkpoint at iteration %d (%d accepted) -> %s_*.npy"

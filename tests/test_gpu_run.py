@@ -261,6 +261,49 @@ def test_batched_chains_are_the_chains_they_would_be_alone(name, n_chains):
             e.close()
 
 
+def test_batched_chains_then_alone_whatever_layers_were_left_pending():
+    """a joint launch that fills the chip keeps TWO pending layers, and after an
+    even number of colour launches since the last flush both are still pending when the call
+    returns (tile_a: 35 colour classes; 2 sweeps = 70 launches).  A context that then runs
+    ALONE -- one layer for its small launches -- must apply them instead of failing, and stay
+    the chain it would have been alone; so must it after an odd count (3 sweeps).  Contexts
+    that rebuild their residual at different sweeps cannot share the pending layers: refused."""
+    from deconv3d_amd import ensemble
+    from tests.cases import make_case
+    case = make_case("tile_a")
+    D, H, W = case["D"], case["H"], case["W"]
+
+    def make(r, refresh_every=0):
+        eng = _lib.Engine((D, H, W), case["fsf"].shape)
+        eng.set_taps(case["fsf"], case["lsf"])
+        eng.set_data(case["data"] * (1.0 + 0.1 * r), case["var"], mask=case["mask"])
+        eng.set_params(case["init"])
+        eng.mh_config(case["min_b"], case["max_b"], 0.1, 40.0 + r, seed=300 + r,
+                      refresh_every=refresh_every)
+        return eng
+
+    for n_batched in (2, 3):
+        with make(1) as eng:
+            eng.mh_sweeps(n_batched + 2, 1)
+            want = (eng.get_params(), eng.download_slot(_lib.SLOT_ERR))
+        engs = [make(r) for r in range(16)]
+        try:
+            ensemble.sweep_chains_batched(engs, n_batched, 1)
+            engs[1].mh_sweeps(2, n_batched + 1)
+            np.testing.assert_array_equal(engs[1].get_params(), want[0])
+            np.testing.assert_array_equal(engs[1].download_slot(_lib.SLOT_ERR), want[1])
+        finally:
+            for e in engs:
+                e.close()
+    engs = [make(0), make(1, refresh_every=5)]
+    try:
+        with pytest.raises(ValueError, match="refresh_every"):
+            ensemble.sweep_chains_batched(engs, 1, 1)
+    finally:
+        for e in engs:
+            e.close()
+
+
 def test_run_is_reproducible_and_seed_sensitive():
     inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
     a = d3d.Run(cube, inst, variance=var, max_iterations=6, seed=11)
