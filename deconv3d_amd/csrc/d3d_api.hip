@@ -243,6 +243,7 @@ int build_colour_lists(d3d_ctx *c) {
         const bool partitioned = c->tiled || !c->part_rects.empty();
         pt.wide = pt.layers == 1 && c->mh_wide && partitioned && c->Dp == 128 && most > 0 &&
                   most <= c->flow_grid / 4 && c->mh_defer == 1;
+        pt.small = pt.layers == 1 && most_wgs < c->flow_grid / 2;
         // k_mh_chain: whole sweeps of the part in one launch of persistent workgroups, one per
         // lattice slot -- where every slot is resident at once (one workgroup per CU) and a
         // thread can hold its share of the window in registers
@@ -411,6 +412,7 @@ const OptDesc g_opts[] = {
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
     {"mh_props", "D3D_MH_PROPS", &d3d_ctx::mh_props, OPT_LAUNCH, 0, 1},
+    {"mh_small", "D3D_MH_SMALL", &d3d_ctx::mh_small, OPT_MH, 0, 1},
     {"halo_timing", "D3D_HALO_TIMING", &d3d_ctx::halo_timing, OPT_LAUNCH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
     {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
@@ -434,7 +436,7 @@ const OptDesc g_opts[] = {
 #ifdef D3D_EXPERIMENTS
     // measured-but-not-faster variants of DESIGN.md section 3 (make EXPERIMENTS=1)
     {"mh_chain", "D3D_MH_CHAIN", &d3d_ctx::mh_chain_opt, OPT_MH, 0, 1},
-    {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 40},
+    {"mh_prio", "D3D_MH_PRIO", &d3d_ctx::mh_prio, OPT_LAUNCH, 0, 255},
     {"mh_maxit", "D3D_MH_MAXIT", &d3d_ctx::mh_maxit_opt, OPT_MH, -1, 32},
     {"mh_flow", "D3D_MH_FLOW", &d3d_ctx::mh_flow, OPT_MH, 0, 1},
     {"mh_pair", "D3D_MH_PAIR", &d3d_ctx::mh_pair, OPT_MH, 0, 1},
@@ -633,7 +635,7 @@ int d3d_ctx_destroy(d3d_ctx *c) {
                     c->dlog, c->hwbuf, c->scal, c->accepted, c->spx, c->gbuf[0], c->gbuf[1], c->gbuf[2], c->gbuf[3],
                     c->flow_ent, c->flow_col, c->flow_lat, c->flow_state, c->flow_err, c->pair_state, c->sep_uv,
                     c->lsf_dense, c->prev, c->recbuf, c->idxbuf, c->extbuf, c->fsf_quad, c->fsf_quad_sep,
-                    c->chain_cols, c->chain_flags, c->chain_G, c->props, c->z_part, c->z_E};
+                    c->chain_cols, c->chain_flags, c->chain_G, c->props, c->z_part, c->z_E, c->ltab, c->ptab};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 #ifdef D3D_EXPERIMENTS
@@ -730,6 +732,7 @@ int d3d_has_experiments(void) {
 
 static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, double thr) {
     HIP_TRY(hipSetDevice(c->device));
+    c->ptab_valid = false;  // (the position tables of k_mh_small hold tap values)
     HIP_TRY(hipMemcpyAsync(c->fsf, fsf, (size_t)c->fh * c->fw * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
     c->fsf_symx = true;
@@ -1306,6 +1309,13 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         P.spx = c->spx + pt.off[col];
         P.rev = (c->mh_zigzag && (ka & 1)) ? 1 : 0;
         if (use_props) P.props = c->props;
+        // (k_mh_small reads the sweep's line table, built with the proposals)
+        if (use_props && pt.small && d3dh::mh_small_usable(c)) {
+            P.ltab = c->ltab;
+            P.ptab = c->ptab;
+            P.ptab_row = d3dh::mh_ptab_row(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
+                                           ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw);
+        }
         if (deferred) {
             // real + virtual positions: the windows of this launch tile the domain
             const int n_all = pt.off[col + 1] - pt.off[col];

@@ -84,6 +84,7 @@ struct d3d_ctx {
         int phase = 0;
         int layers = 1;                          // pending layers in use
         bool wide = false;                       // its colour launches take the wide form (MH_WIDE_NS)
+        bool small = false;                      // its colour launches do not fill the chip: k_mh_small
         // k_mh_chain (whole sweeps of the part in one launch): slot grid, or chain = false
         bool chain = false;
         int chain_ns = 0, chain_sx0 = 0, n_sy = 0, n_sx = 0, K = 0;
@@ -186,6 +187,10 @@ struct d3d_ctx {
     d3d::MHProposal *props = nullptr;  // [HW]
     long props_sweep = -1;         // the sweep (Philox number) the table holds, -1 = none
     int mh_prio = 0;               // option mh_prio: staggered completion by wave priority (MHArgs::prio)
+    int mh_small = 1;              // option mh_small = 0: small colour launches keep round 3's k_mh_ws variants instead of k_mh_small
+    double *ptab = nullptr;        // [(fh fw + 1)][fh fw][4] relative position tables of k_mh_small (ensure_proposals)
+    bool ptab_valid = false;       // (d3d_set_taps invalidates them)
+    double *ltab = nullptr;        // [HW][2][Dp] line table of the current sweep (k_mh_line_table), allocated on first use
     int mh_wide = 1;               // option mh_wide = 0: never the wide form for the small launches of a partitioned context
     int mh_pair = 0;               // D3D_MH_PAIR=1: two colour classes per launch (k_mh_pair;
                                    // measured 43.0 vs 42.0 us per colour: opt-in)
@@ -281,6 +286,10 @@ int launch_mh_defer(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
 int flush_pending(d3d_ctx *c);
 // the proposals of sweep `sweep` for every owned spaxel (MHArgs::props), once per sweep
 int ensure_proposals(d3d_ctx *c, uint32_t sweep);
+// k_mh_small can take this context's small parts (depth, tap count, options)
+bool mh_small_usable(const d3d_ctx *c);
+// row of the position tables for a launch of local colour residues (ly, lx) over the pending layer
+int mh_ptab_row(const d3d_ctx *c, int ly, int lx);
 // n_sweeps whole sweeps (Philox numbers sweep0 ..) of part pi in one launch (Part::chain)
 #ifdef D3D_EXPERIMENTS
 int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps);

@@ -1657,6 +1657,16 @@ struct MHArgs {
     // colour's windows finish streaming before the other half, so that their decisions
     // overlap the others' streams (measured flat: DESIGN.md section 3).
     int prio;
+    // k_mh_small (round 4, csrc/d3d_mh_small.h): the sweep's LINE TABLE, [H*W][2][Dp] -- the
+    // LSF-convolved unit lines of every spaxel's current and proposed (c, w), built with the
+    // proposals by k_mh_line_table before the sweep's first colour -- and ceil(2^16 / fw), for
+    // position -> (row, column) of the window without a division.
+    const double *ltab;
+    int fw_inv;
+    // ... and the relative position tables of the context (d3d_mh_small.h: MHPos), with the
+    // row of this launch's pair of colour classes
+    const double *ptab;
+    int ptab_row;
 #ifdef D3D_EXPERIMENTS
     // k_mh_ws phase stamps (100 MHz wall clock), 8 slots per workgroup: 0 entry,
     // 1 setup done, 2 window streamed, 3 prepare wavefront done, 4 update written
@@ -1683,6 +1693,7 @@ constexpr int MH_WS_MAX_DP = 512;  // deepest cube k_mh_ws takes (512 streaming 
 // EXPERIMENTS builds only: even the untaken test costs the default kernel 0.7 us per launch
 // (the launch's first instructions wait for one more kernel argument).
 __device__ __forceinline__ void mh_stagger(int prio) {
+    prio &= 63;  // (bits 6, 7: timing-only switches of mh_ws_run)
     if (prio <= 0) return;
     if (prio < 16) {
         if ((blockIdx.x >> (prio - 1)) & 1) __builtin_amdgcn_s_setprio(2);
@@ -1828,18 +1839,18 @@ __device__ __forceinline__ void mh_lsf(const MHArgs &P, const double *gO, const 
 //   mh_decide_wave    ONE wavefront (every lane the same numbers): totals, accept,
 //                     Gibbs draw; state written, verdict left in LDS
 //   mh_update_coeff   thread <-> channel: the residual update coefficient G[z]
-__device__ __forceinline__ void mh_channel_sums(const MHArgs &P, const MHShared &S,
-                                                const MHProposal &q, int ch, int G, double EO,
-                                                double EN, int first) {
+// (the seven sums of this thread's wavefront, valid in lane 63; `red`: the group partial sums)
+__device__ __forceinline__ void mh_channel_sums_regs(const MHArgs &P, const double *red,
+                                                     const MHProposal &q, int ch, int G, double EO,
+                                                     double EN, double (&sums)[7]) {
     const int Dp = P.Dp, D = P.D;
-    double sums[7];
     const double a_new = q.pn[0];  // the proposal keeps the amplitude (amp[0] = 0 with Gibbs)
     const double Lo = q.a_old * EO;
     double Az = 0.0, Bz = 0.0, Cz = 0.0;
     if (ch < D) {
 #pragma unroll 4
         for (int gg = 0; gg < G; ++gg) {
-            const double *r = S.red + (size_t)gg * 3 * Dp + ch;
+            const double *r = red + (size_t)gg * 3 * Dp + ch;
             Az += r[0];
             Bz += r[Dp];
             Cz += r[2 * Dp];
@@ -1856,10 +1867,63 @@ __device__ __forceinline__ void mh_channel_sums(const MHArgs &P, const MHShared 
     sums[6] = EN * ulB;
 #pragma unroll
     for (int k = 0; k < 7; ++k) sums[k] = wave_sum_dpp63(sums[k]);
+}
+
+__device__ __forceinline__ void mh_channel_sums(const MHArgs &P, const MHShared &S,
+                                                const MHProposal &q, int ch, int G, double EO,
+                                                double EN, int first) {
+    double sums[7];
+    mh_channel_sums_regs(P, S.red, q, ch, G, EO, EN, sums);
     const int wave = (threadIdx.x >> 6) - first;
     if ((threadIdx.x & 63) == 63) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) S.sum[wave * 8 + k] = sums[k];
+    }
+}
+
+// The decision proper, from the seven totals (every lane of the calling wavefront the same
+// numbers): accept, Gibbs draw; the lanes with `writes` set store the new state.
+__device__ __forceinline__ void mh_decide_core(const MHArgs &P, const MHProposal &q, int sp,
+                                               uint32_t sweep, const double (&tot)[7],
+                                               const U2 &u_gibbs, bool writes, bool *accept_out,
+                                               double *r_out) {
+    const double delta = -tot[0] - 0.5 * tot[1];  // ar_old - ar_new, lib/run.py:426
+    // ---- MH accept (lib/run.py:435-445) --------------------------------
+    const bool accept = (q.log_u < delta) && !q.oob;
+    // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
+    const double s_ee = accept ? tot[5] : tot[3];
+    const double s_eu = accept ? tot[6] : tot[4];
+    // ---- Gibbs draw of the amplitude (lib/run.py:456-499) --------------
+    double r;
+    if (P.ext_lines && !P.ext_gibbs) {
+        r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
+    } else {
+        const double ro = P.ra / (1.0 + P.ra * s_ee);
+        const double mu = ro * s_eu;
+        uint32_t blk = BLK_GIBBS;
+        r = truncated_normal<true>(P.min_b[0], P.max_b[0], mu, sqrt(ro), u_gibbs, P.seed, q.gsp,
+                                   sweep, &blk);
+    }
+    *accept_out = accept;
+    *r_out = r;
+    if (writes) {
+        if (P.ext_lines) {
+            double *o3 = P.ext_out + (long)blockIdx.x * 3;
+            o3[0] = accept ? 1.0 : 0.0;
+            o3[1] = r;
+            o3[2] = delta;
+        } else {
+            if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
+                P.prev[(long)sp * 3 + 0] = q.a_old;
+                P.prev[(long)sp * 3 + 1] = q.c_old;
+                P.prev[(long)sp * 3 + 2] = q.w_old;
+            }
+            P.params[(long)sp * 3 + 0] = r;
+            P.params[(long)sp * 3 + 1] = accept ? q.pn[1] : q.c_old;
+            P.params[(long)sp * 3 + 2] = accept ? q.pn[2] : q.w_old;
+        }
+        P.dlog[sp] = delta;
+        if (accept) atomicAdd(P.accepted, 1ULL);
     }
 }
 
@@ -1891,42 +1955,12 @@ __device__ __forceinline__ void mh_decide_wave(const MHArgs &P, const MHShared &
         }
         return;
     }
-    // ---- MH accept (lib/run.py:435-445) --------------------------------
-    const bool accept = (q.log_u < delta) && !q.oob;
-    // after an accepted move err = ul - a_new*f*E_new, ul is unchanged
-    const double s_ee = accept ? tot[5] : tot[3];
-    const double s_eu = accept ? tot[6] : tot[4];
-    // ---- Gibbs draw of the amplitude (lib/run.py:456-499) --------------
+    bool accept;
     double r;
-    if (P.ext_lines && !P.ext_gibbs) {
-        r = q.a_old;  // model without a Gibbs amplitude: the lines are absolute
-    } else {
-        const double ro = P.ra / (1.0 + P.ra * s_ee);
-        const double mu = ro * s_eu;
-        uint32_t blk = BLK_GIBBS;
-        r = truncated_normal<true>(P.min_b[0], P.max_b[0], mu, sqrt(ro), u_gibbs, P.seed, q.gsp,
-                                   sweep, &blk);
-    }
+    mh_decide_core(P, q, sp, sweep, tot, u_gibbs, lead, &accept, &r);
     if (lead) {
         verdict[0] = accept ? 1.0 : 0.0;
         verdict[1] = r;
-        if (P.ext_lines) {
-            double *o3 = P.ext_out + (long)blockIdx.x * 3;
-            o3[0] = accept ? 1.0 : 0.0;
-            o3[1] = r;
-            o3[2] = delta;
-        } else {
-            if (P.prev) {  // remembered for d3d_export_updates (tiled multi-GPU replay)
-                P.prev[(long)sp * 3 + 0] = q.a_old;
-                P.prev[(long)sp * 3 + 1] = q.c_old;
-                P.prev[(long)sp * 3 + 2] = q.w_old;
-            }
-            P.params[(long)sp * 3 + 0] = r;
-            P.params[(long)sp * 3 + 1] = accept ? q.pn[1] : q.c_old;
-            P.params[(long)sp * 3 + 2] = accept ? q.pn[2] : q.w_old;
-        }
-        P.dlog[sp] = delta;
-        if (accept) atomicAdd(P.accepted, 1ULL);
     }
 }
 
@@ -1947,7 +1981,8 @@ __device__ __forceinline__ double mh_update_coeff(const MHArgs &P, const MHShare
 __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, const MHProposal &q,
                                           int sp, uint32_t sweep, int ch, int G, double EO,
                                           double EN, int first, int nw, bool caller,
-                                          double *Gz_out, const U2 *u_pre = nullptr) {
+                                          double *Gz_out, const U2 *u_pre = nullptr,
+                                          long stamp_at = -1) {
     // the uniforms of the Gibbs draw depend on nothing the window pass produces:
     // drawn here, ahead of the barrier, they are off the critical tail
     U2 u_gibbs = {0.5, 0.5};
@@ -1956,8 +1991,10 @@ __device__ __forceinline__ bool mh_finish(const MHArgs &P, const MHShared &S, co
         mh_channel_sums(P, S, q, ch, G, EO, EN, first);
     }
     __syncthreads();
+    if (stamp_at >= 0) D3D_MH_STAMP(stamp_at, 6, 0);  // channel sums in LDS
     if (caller && (int)(threadIdx.x >> 6) == first) mh_decide_wave(P, S, q, sp, sweep, nw, u_gibbs);
     __syncthreads();
+    if (stamp_at >= 0) D3D_MH_STAMP(stamp_at, 7, 0);  // verdict in LDS
     if (!caller || P.probe) {
         *Gz_out = 0.0;
         return false;
@@ -2489,7 +2526,11 @@ __device__ __forceinline__ void mh_ws_prefetch(const MHArgs &P, const MHWsItem &
         }
         const long idx = (long)max(R.vox[u], 0) * (ZBK ? zs : (long)Dp) + 2 * zl;
         R.e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
+#ifdef D3D_EXPERIMENTS
+        if (!UV && !(P.prio & 128)) R.v[u] = mh_load_ivar<NTV>(P.ivar + idx);
+#else
         if (!UV) R.v[u] = mh_load_ivar<NTV>(P.ivar + idx);
+#endif
     }
 }
 
@@ -2584,7 +2625,12 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                         e[u] = *reinterpret_cast<const double2 *>(P.err + idx);
                     }
                     v[u] = vu;
+#ifdef D3D_EXPERIMENTS
+                    // timing-only switch (wrong results): mh_prio bit 7 -- no 1/variance loads
+                    if (!UV && !(P.prio & 128)) v[u] = mh_load_ivar<NTV>(P.ivar + idx);
+#else
                     if (!UV) v[u] = mh_load_ivar<NTV>(P.ivar + idx);
+#endif
                 }
             };
             auto consume = [&](int p0, int (&vox)[U], double2 (&e)[U], double2 (&v)[U]) {
@@ -2608,6 +2654,10 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                             touched = true;
                         }
                     }
+#ifdef D3D_EXPERIMENTS
+                    // timing-only switch (wrong results): mh_prio bit 6 -- no residual stores
+                    if (P.prio & 64) touched = false;
+#endif
                     if (touched && I.write_back) {
                         // (NTV, a context beyond the Infinity Cache: write-through as well --
                         // no dirty lines left for the end of the kernel to flush; 300x300x256
@@ -2637,7 +2687,10 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                 consume(p0, vox, e, v);
                 p0 += U * G;
             }
-#pragma unroll 4
+            // (the deep-prefetch forms, U >= 8, hold a thread's whole window share in one or two
+            // rounds: nothing to unroll)
+            constexpr int UNR = U >= 8 ? 1 : 4;
+#pragma unroll UNR
             for (; p0 < P.npos; p0 += U * G) {
                 int vox[U];
                 double2 e[U], v[U];
@@ -2716,7 +2769,8 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
         return;
     }
     double Gt;
-    if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs)) return;
+    if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs, stamp_at))
+        return;
     if (tid < Dp) {
         double *dst = I.Gcur + ((long)(I.y / P.fh) * P.slots_x + I.x / P.fw) * Dp + tid;
         if (COHG)
@@ -2816,6 +2870,11 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     const MHShared S = mh_carve(smem, NS, P.HL, P.Dp, P.N, P.npos, M);
     D3D_MH_STAMP(blockIdx.x, 0, 0);
 #ifdef D3D_EXPERIMENTS
+    // where the workgroup runs: HW_ID (wave, SIMD, CU, SH, SE) | XCC_ID << 32
+    if (P.stamp && threadIdx.x == 0)
+        P.stamp[(long)blockIdx.x * 8 + 5] =
+            (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);
     mh_stagger(P.prio);
 #endif
     const int4 ent = P.spx[BATCH ? item : (int)blockIdx.x];
@@ -2843,8 +2902,8 @@ __global__ __launch_bounds__(NS + 64) void k_mh_ws(MHArgs P, uint32_t sweep) {
     mh_ws_gp_store<M, K>(P, S, I, NT, gv);
     __syncthreads();
     D3D_MH_STAMP(blockIdx.x, 1, 0);
-    // (U = 4 or the wide form: the variants of launches that do not fill the chip)
-    mh_ws_run<NS, UV, false, U, M, false, true, NTV, (U == 4 || NS != 256)>(P, S, I, sweep, blockIdx.x,
+    // (U >= 4 or the wide form: the variants of launches that do not fill the chip)
+    mh_ws_run<NS, UV, false, U, M, false, true, NTV, (U >= 4 || NS != 256)>(P, S, I, sweep, blockIdx.x,
                                                                            &pre);
 }
 

@@ -1,5 +1,6 @@
 // Launchers of the MH-within-Gibbs kernels (d3d_kernels.h).  gfx950 only.
 #include "d3d_ctx.h"
+#include "d3d_mh_small.h"
 
 namespace d3dh {
 
@@ -52,6 +53,10 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.rev = 0;
     P.prio = c->mh_prio;
     P.props = nullptr;  // (run_part sets it for the parts whose colour launches are small)
+    P.ltab = nullptr;   // (and the line table for those that run k_mh_small)
+    P.fw_inv = (65536 + c->fw - 1) / c->fw;
+    P.ptab = nullptr;
+    P.ptab_row = c->fh * c->fw;
     P.batch = nullptr;  // (mh_sweeps_batch)
     P.b_items = 0;
     P.b_gcur = 0;
@@ -166,6 +171,9 @@ int launch_mh_defer_nt(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t
 
 template <bool UV, int U, int M, int K, bool NTV = false, int NS = 256>
 int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    // (round 4, measured: the workgroups of a small launch already run on distinct compute
+    // units -- HW_ID stamps, tools/mh_tail.py -- so asking for more than half of a CU's LDS to
+    // force that changes nothing)
     const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
     hipError_t attr = hipSuccess;
     auto go = [&](auto kern) {
@@ -194,6 +202,82 @@ int launch_mh_ws_um(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
     return 0;
 }
 
+// k_mh_small (d3d_mh_small.h): colour launches that do not fill the chip, one pending layer.
+// 256 streaming threads, or -- `wide`, 128 channels in a partitioned context -- 704.
+bool mh_small_usable(const d3d_ctx *c) {
+    // thread t <-> channel t in the tail; window rows / columns as bits of a 32-bit mask;
+    // 32-bit byte offsets into the residual
+    return c->mh_small && c->mh_props && c->mh_defer == 1 && !c->mh_zb && !c->deep && c->Dp <= 256 &&
+           c->fh <= 31 && c->fw <= 31 && (double)c->cube_elems * 8.0 < 4294967296.0;
+}
+
+int mh_ptab_row(const d3d_ctx *c, int ly, int lx) {
+    if (c->lay_n < 1) return c->fh * c->fw;  // nothing pending
+    const int fhh = (c->fh - 1) / 2, fhw = (c->fw - 1) / 2;
+    // any window of the class: the offset of the covering pending spaxel is the same for all
+    const int y = ly + 4 * c->fh, x = lx + 4 * c->fw;
+    const int oy = d3d::mh_raw_cover(y - fhh, c->lay_cy[c->lay_n - 1], c->fh, fhh) - (y - fhh);
+    const int ox = d3d::mh_raw_cover(x - fhw, c->lay_cx[c->lay_n - 1], c->fw, fhw) - (x - fhw);
+    return (oy + fhh) * c->fw + (ox + fhw);
+}
+
+// The relative position tables of k_mh_small (d3d_mh_small.h: MHPos), once per set of taps.
+static int ensure_ptab(d3d_ctx *c) {
+    if (c->ptab_valid) return 0;
+    const int fh = c->fh, fw = c->fw, npos = fh * fw, fhh = (fh - 1) / 2, fhw = (fw - 1) / 2;
+    std::vector<double> tab((size_t)(npos + 1) * npos * 4, 0.0);
+    for (int row = 0; row <= npos; ++row) {
+        const int oy = row / fw - fhh, ox = row % fw - fhw;
+        for (int p = 0; p < npos; ++p) {
+            const int dy = p / fw, dx = p % fw;
+            int sel = 0, has = 0;
+            double fp = 0.0;
+            if (row < npos) {
+                const int hy = dy > oy + fhh, hx = dx > ox + fhw;
+                const int trow = dy - oy - hy * fh + fhh, tcol = dx - ox - hx * fw + fhw;
+                sel = 2 * hy + hx;
+                has = 1;
+                fp = c->h_fsf[(size_t)trow * fw + tcol];
+            }
+            const int rel = (dy - fhh) * c->W + (dx - fhw);
+            const unsigned pk = d3d::mh_pos_pack(dy, dx, sel, has);
+            const unsigned long long bits = ((unsigned long long)pk << 32) | (unsigned)rel;
+            double first;
+            memcpy(&first, &bits, sizeof first);
+            double *e = &tab[((size_t)row * npos + p) * 4];
+            e[0] = c->h_fsf[p];
+            e[1] = fp;
+            e[2] = first;
+        }
+    }
+    if (!c->ptab) HIP_TRY(hipMalloc(&c->ptab, tab.size() * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(c->ptab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `tab` goes out of scope
+    c->ptab_valid = true;
+    return 0;
+}
+
+template <bool UV, int NS, int U, int K>
+int launch_mh_small_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
+    const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_small<NS, UV, U, K>), dim3(grid), dim3(NS), lds, c->stream,
+                       P, sweep);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <bool UV>
+int launch_mh_small(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, bool wide) {
+    NEED(P.n_lay <= 1 && P.ltab && P.props, D3D_ERR_STATE, "internal: k_mh_small with %d pending layers", P.n_lay);
+    // Eight window positions (sixteen loads) in flight per thread, six in the wide form (704
+    // threads leave 168 registers; eleven spilled: 15.9 us per launch against 11.9).  Measured
+    // beside it at 64^3: four 11.0 us, eight 10.5, sixteen (250 registers) 10.4.
+    if (wide) return launch_mh_small_t<UV, MH_WIDE_NS, 6, 1>(c, P, grid, sweep);
+    if (c->Dp <= 64) return launch_mh_small_t<UV, 256, 8, 1>(c, P, grid, sweep);
+    if (c->Dp <= 128) return launch_mh_small_t<UV, 256, 8, 2>(c, P, grid, sweep);
+    return launch_mh_small_t<UV, 256, 8, 4>(c, P, grid, sweep);
+}
+
 // A launch that does not fill the chip (fewer workgroups than 2 per CU) is
 // latency-bound: four window positions in flight per wavefront instead of one.
 // The kernels for several pending layers need more LDS; with one layer
@@ -208,6 +292,8 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // (the uniform-variance variant also gains from the deeper queue at full size:
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
+    // (round 4: the parts whose launches do not fill the chip -- run_part hands them the line table)
+    if (P.ltab && layers == 1) return launch_mh_small<UV>(c, P, grid, sweep, wide);
     // 257 .. 512 channels (round 3): the same kernel with 512 streaming threads (thread <->
     // channel in the tail; the staged G rows, 4 Dp <= 4 x 576, in four registers); the position
     // groups (512 / HL) are those of k_mh_defer<512>, so the chain stays bit-identical to it
@@ -274,6 +360,10 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // the single context given the same parts still agree to the last bit.  Shallow cubes lose
     // (32 channels: 9.9 -> 12.2 us per launch).  Option mh_wide = 0: off.
     // (decided per PART, Part::wide, so that every colour of a part groups the window sums alike)
+    // (round 4, measured and dropped: ALL of a thread's positions requested before the setup --
+    // U = 16 / 8 / 11 here -- 64^3 12.5 -> 13.2 us per launch, an 8x1 strip 14.2 -> 16.6: this
+    // kernel's window pass is bound by instruction issue, not by round trips; k_mh_small,
+    // d3d_mh_small.h, is what came of it)
     if (small && wide) return launch_mh_ws_um<UV, 1, 1, 1, false, MH_WIDE_NS>(c, P, grid, sweep);
     if (small) return launch_mh_ws_um<UV, 4, 1, 4>(c, P, grid, sweep);
     return launch_mh_ws_um<UV, 1, 1, 4>(c, P, grid, sweep);
@@ -605,7 +695,19 @@ int ensure_proposals(d3d_ctx *c, uint32_t sweep) {
     d3d::MHArgs P;
     fill_mh_args(c, P);
     const int n = (c->oy1 - c->oy0) * (c->ox1 - c->ox0);
-    if (n > 0) {
+    // with the lines of every update where a part runs k_mh_small (one wavefront per spaxel)
+    bool lines = false;
+    if (mh_small_usable(c))
+        for (const d3d_ctx::Part &pt : c->parts) lines = lines || pt.small;
+    if (lines && !c->ltab) HIP_TRY(hipMalloc(&c->ltab, (size_t)c->HW * 2 * c->Dp * sizeof(double)));
+    if (lines)
+        if (int rc = ensure_ptab(c)) return rc;
+    if (n > 0 && lines) {
+        const size_t lds = (size_t)4 * 2 * c->N * sizeof(double);
+        hipLaunchKernelGGL(d3d::k_mh_line_table, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, c->stream, P,
+                           sweep, c->oy0, c->oy1, c->ox0, c->ox1, c->props, c->ltab);
+        HIP_TRY(hipGetLastError());
+    } else if (n > 0) {
         hipLaunchKernelGGL(d3d::k_mh_proposals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            P, sweep, c->oy0, c->oy1, c->ox0, c->ox1, c->props);
         HIP_TRY(hipGetLastError());

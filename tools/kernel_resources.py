@@ -19,31 +19,36 @@ LIB = os.path.join(HERE, "..", "deconv3d_amd", "csrc", "libdeconv3d_hip.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def device_code_object(path):
+def device_code_objects(path):
+    """Every gfx950 code object of the library: one offload bundle per translation unit."""
     data = open(path, "rb").read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"
-    at = data.find(magic)
-    if at < 0:
-        raise SystemExit("no offload bundle in %s" % path)
-    (n,) = struct.unpack_from("<Q", data, at + len(magic))
-    off = at + len(magic) + 8
-    for _ in range(n):
-        o, size, tl = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        triple = data[off:off + tl]
-        off += tl
-        if b"gfx950" in triple:
-            return data[at + o:at + o + size]
-    raise SystemExit("no gfx950 code object in %s" % path)
+    out, at = [], data.find(magic)
+    while at >= 0:
+        (n,) = struct.unpack_from("<Q", data, at + len(magic))
+        off = at + len(magic) + 8
+        for _ in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl]
+            off += tl
+            if b"gfx950" in triple:
+                out.append(data[at + o:at + o + size])
+        at = data.find(magic, at + len(magic))
+    if not out:
+        raise SystemExit("no gfx950 code object in %s" % path)
+    return out
 
 
 def main(argv):
     wanted = argv[1:]
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(device_code_object(LIB))
-        f.flush()
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name],
-                               capture_output=True, text=True, check=True).stdout
+    notes = ""
+    for blob in device_code_objects(os.environ.get("DECONV3D_HIP_LIB", LIB)):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            notes += subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f.name],
+                                    capture_output=True, text=True, check=True).stdout
     rows = []
     for block in notes.split("- .agpr_count")[1:]:
         name = re.search(r"\.name:\s+(\S+)", block).group(1)
