@@ -287,7 +287,11 @@ def finish_tiled_leg(leg, rank):
                     "phases_per_sweep": rec.get("phases_per_sweep"),
                     "rccl_ranks": rec.get("rccl_ranks"),
                     "halo_ms_per_sweep": rec.get("halo_ms_per_sweep"),
-                    "verified_against": rec.get("verified_against")}
+                    "verified_against": rec.get("verified_against"),
+                    # compute side: sum over the phases of the slowest rank's own time
+                    "projected_critical_path_ms": rec.get("projected_critical_path_ms"),
+                    "slowest_rank": rec.get("slowest_rank"),
+                    "critical_path_by_phase": rec.get("critical_path_by_phase")}
     errf.seek(0)
     tail = errf.read().decode(errors="replace").strip().splitlines()[-3:]
     return {"error": "tiled leg exited with code %s" % proc.returncode, "stderr_tail": tail}
@@ -404,46 +408,39 @@ def mh_cube_leg(args, local_rank, fs, shape, label, traffic_key):
 
 
 def batched_chains_leg(args, local_rank, chains=16, workload="c2_64x64x64"):
-    """BASELINE config 2's cube as an ENSEMBLE on one GPU: `chains` independent chains (other
-    seeds) in ONE launch per colour class (d3d_mh_sweeps_batch).  A single chain of that cube
-    is a latency chain of 121 small launches (49 windows for 1024 workgroup slots); the joint
-    launch carries 16 times the windows for about the same latency.  Aggregate rate; every chain
-    is bit-identical to the chain run alone (tests/test_gpu_run.py)."""
+    """BASELINE config 2's cube as an ENSEMBLE on one GPU, through the drop-in API:
+    `Run(..., chains=16)` -- 16 independent chains (seeds seed + r) in ONE launch per colour
+    class (d3d_mh_sweeps_batch).  A single chain of that cube is a latency chain of 121 small
+    launches (49 windows for 1024 workgroup slots); the joint launch carries 16 times the
+    windows for about the same latency.  Aggregate rate over the wall time of the runs' device
+    calls (`Run.mh_seconds`: the MH loop, setup and outputs excluded); chain r is bit-identical
+    to the chain of `Run(..., seed=seed + r)` (tests/test_gpu_run.py)."""
+    import logging
+    import deconv3d_amd as d3d
     from deconv3d_amd import _lib
+    logging.getLogger("deconv3d").setLevel(logging.WARNING)
     D, H, W, fs = WORKLOADS[workload]
     fsf, lsf = build_taps(D, fs)
-    engs, inits = [], []
-    try:
-        for r in range(chains):
-            eng = _lib.Engine((D, H, W), fsf.shape, device=local_rank)
-            engs.append(eng)
-            eng.set_taps(fsf, lsf)
-            data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 4000 + r)
-            eng.set_data(data, var, mask=None)
-            eng.set_params(init)
-            inits.append(init)
-            eng.mh_config(min_b, max_b, 0.1, float(max_b[0] ** 2), seed=4000 + r, refresh_every=0)
-        steps = max(20, min(10 * args.steps, 200))
-        single = engs[0]
-        single.residual(fetch=False)
-        single.mh_sweeps(5, 1)
-        single.sync()
-        t0 = time.perf_counter()
-        single.mh_sweeps(steps, 6)
-        one = steps * H * W / (time.perf_counter() - t0)
-        single.set_params(inits[0])
-        _lib.mh_sweeps_batch(engs, 5, 1)
-        t0 = time.perf_counter()
-        acc = _lib.mh_sweeps_batch(engs, steps, 6)
-        dt = time.perf_counter() - t0
-        return {"workload": workload, "chains": chains, "value": round(chains * steps * H * W / dt, 1),
-                "unit": "spaxel-updates/s", "ms_per_sweep_of_all_chains": round(dt * 1e3 / steps, 4),
-                "one_chain_alone": round(one, 1), "acceptance": round(sum(acc) / (chains * steps * H * W), 3),
-                "note": "extra: %d independent chains of one geometry in one launch per colour class "
-                        "(wall clock around the call); not `value`" % chains}
-    finally:
-        for e in engs:
-            e.close()
+    with _lib.Engine((D, H, W), fsf.shape, device=local_rank) as eng:
+        eng.set_taps(fsf, lsf)
+        data, var, truth, init, min_b, max_b = synthetic_inputs(eng, D, H, W, fsf, 4000)
+    inst = d3d.Instrument(d3d.VectorLineSpreadFunction(lsf), d3d.ImageFieldSpreadFunction(fsf))
+    cube = d3d.MUSE().build_cube(data)
+    steps = max(20, min(10 * args.steps, 200))
+    kw = dict(variance=var, max_iterations=steps + 1, keep_one_in=steps, min_acceptance_rate=0.,
+              seed=4000, device=local_rank, refresh_every=0)
+    d3d.Run(cube, inst, chains=chains, **dict(kw, max_iterations=6))          # warm (clocks, allocations)
+    many = d3d.Run(cube, inst, chains=chains, **kw)
+    one = d3d.Run(cube, inst, **kw)
+    rate = chains * steps * H * W / many.mh_seconds
+    return {"workload": workload, "chains": chains, "value": round(rate, 1),
+            "unit": "spaxel-updates/s", "via": "Run(cube, instrument, chains=%d)" % chains,
+            "ms_per_sweep_of_all_chains": round(many.mh_seconds * 1e3 / steps, 4),
+            "one_chain_alone": round(steps * H * W / one.mh_seconds, 1),
+            "acceptance": round(float(np.mean(many.acceptance_rates)), 3),
+            "chain0_equals_the_single_run": bool(np.array_equal(many.chains[0], one.chain)),
+            "note": "extra: %d independent chains of one cube in one launch per colour class "
+                    "(wall clock of the runs' device calls); not `value`" % chains}
 
 
 def conv_beyond_mall_leg(args, local_rank, fs):

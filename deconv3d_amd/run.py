@@ -67,7 +67,17 @@ class Run:
     checkpoint's ``<prefix>_parameters.npy`` as ``initial_parameters``), and
     ``chain_file`` (file prefix: chain and likelihoods live in memory-mapped
     ``<prefix>_chain.npy`` / ``<prefix>_likelihoods.npy`` instead of RAM, written as the
-    device streams saved sweeps out -- a 300x300 chain of 50 000 sweeps is 108 GB).
+    device streams saved sweeps out -- a 300x300 chain of 50 000 sweeps is 108 GB), and
+    ``chains`` (R >= 2 independent chains of the same cube, seeds ``seed + r``, advanced
+    TOGETHER: a cube whose colour launches leave the chip idle -- the reference's own fixtures
+    are 24x30x21 -- runs R chains in about the time of one, see `chains` below).
+
+    With ``chains=R``: ``run.chains[r]`` / ``run.all_likelihoods[r]`` are chain r's arrays
+    (``run.chain`` / ``run.likelihoods`` are chain 0's; chain r is bit for bit the chain of
+    ``Run(..., seed=seed + r)``), ``extract_parameters`` pools the chains, ``run.rhat`` is the
+    per-parameter Gelman-Rubin map, ``run.acceptance_rates`` the per-chain rates; the stopping
+    rule looks at the pooled acceptance rate.  ``initial_parameters`` may be 4-D, one map per
+    chain.  Checkpoints and custom (host-evaluated) line models take one chain.
     """
 
     def __init__(
@@ -91,6 +101,7 @@ class Run:
         checkpoint=None,
         resume_state=None,
         chain_file=None,
+        chains=1,
     ):
         # lib/run.py:112-114
         assert keep_one_in > 0, "keep_one_in= MUST be a positive integer"
@@ -100,6 +111,11 @@ class Run:
         self.keep_one_in = int(keep_one_in)
         self.max_iterations = int(max_iterations)
         self.write_every = int(write_every)
+        n_chains = int(chains)
+        assert n_chains >= 1, "chains= MUST be a positive integer"
+        if n_chains > 1 and (checkpoint is not None or resume_state is not None):
+            raise NotImplementedError("checkpoint= / resume_state= take one chain (chains=1)")
+        self.n_chains = n_chains
 
         # ---- input cube (lib/run.py:119-143) --------------------------------
         if isinstance(cube, str):
@@ -202,29 +218,40 @@ class Run:
         self.seed = int(seed)
 
         # ---- chain storage (lib/run.py:267-281), NaN instead of garbage ------
+        # (one chain array per chain; chain r > 0 of a memory-mapped run lives in <prefix>_c<r>_*)
         self._chain_file = chain_file
+        self._likelihoods_maps = []
+        self.chains, all_likelihoods = [], []
         try:
             chain_shape = (cnt_iterations, cube_height, cube_width, parameters_count)
-            if chain_file is not None:
-                # pages are created as saved sweeps arrive; slots never written (early
-                # stop) are NaN-filled at the end like the in-memory chain
-                self.chain = np.lib.format.open_memmap(
-                    "%s_chain.npy" % chain_file, mode="w+", dtype=np.float64, shape=chain_shape)
-                likelihoods = np.lib.format.open_memmap(
-                    "%s_likelihoods.npy" % chain_file, mode="w+", dtype=np.float64,
-                    shape=chain_shape[:3])
-                likelihoods[0] = np.nan
-                self._likelihoods_map = likelihoods
-            else:
-                self.chain = np.full(chain_shape, np.nan)
-                likelihoods = np.full(chain_shape[:3], np.nan)
+            for r in range(n_chains):
+                if chain_file is not None:
+                    # pages are created as saved sweeps arrive; slots never written (early
+                    # stop) are NaN-filled at the end like the in-memory chain
+                    prefix = chain_file if r == 0 else "%s_c%d" % (chain_file, r)
+                    ch = np.lib.format.open_memmap(
+                        "%s_chain.npy" % prefix, mode="w+", dtype=np.float64, shape=chain_shape)
+                    lk = np.lib.format.open_memmap(
+                        "%s_likelihoods.npy" % prefix, mode="w+", dtype=np.float64,
+                        shape=chain_shape[:3])
+                    lk[0] = np.nan
+                    self._likelihoods_maps.append(lk)
+                else:
+                    ch = np.full(chain_shape, np.nan)
+                    lk = np.full(chain_shape[:3], np.nan)
+                self.chains.append(ch)
+                all_likelihoods.append(lk)
         except MemoryError:
             self.logger.error("Not enough RAM available for that many iterations. "
                               "Use a higher value in the keep_one_in= parameter.")
             raise
+        self.chain = self.chains[0]
+        likelihoods = all_likelihoods[0]
+        self._likelihoods_map = self._likelihoods_maps[0] if self._likelihoods_maps else None
 
         # ---- initial parameters (lib/run.py:293-314) -------------------------
-        rng = np.random.default_rng(self.seed)
+        # (chain r draws its start from the generator of seed + r: it is the chain of
+        # Run(..., seed=seed + r))
         if initial_parameters is not None:
             if isinstance(initial_parameters, str):
                 initial_parameters = np.load(initial_parameters)
@@ -234,20 +261,35 @@ class Run:
                     raise ValueError("1D initial params MUST have %d values, got %d."
                                      % (parameters_count, initial_parameters.shape[0]))
                 initial_parameters = np.tile(initial_parameters, (cube_height, cube_width, 1))
-            ip_shape = initial_parameters.shape
+            per_chain = initial_parameters.ndim == 4
+            if per_chain and initial_parameters.shape[0] != n_chains:
+                raise ValueError("4D initial params MUST hold one map per chain (%d), got %d."
+                                 % (n_chains, initial_parameters.shape[0]))
+            ip_shape = initial_parameters.shape[1:] if per_chain else initial_parameters.shape
             if ip_shape[0] != cube_height or ip_shape[1] != cube_width:
                 raise ValueError("Initial params MUST have (%d, %d) shape, got (%d, %d)."
                                  % (cube_height, cube_width, ip_shape[0], ip_shape[1]))
-            self.chain[0] = initial_parameters
+            for r in range(n_chains):
+                self.chains[r][0] = initial_parameters[r] if per_chain else initial_parameters
         else:
-            draws = rng.random((cube_height, cube_width, parameters_count))
-            self.chain[0] = min_boundaries + (max_boundaries - min_boundaries) * draws
+            for r in range(n_chains):
+                draws = np.random.default_rng(self.seed + r).random(
+                    (cube_height, cube_width, parameters_count))
+                self.chains[r][0] = min_boundaries + (max_boundaries - min_boundaries) * draws
 
         # ---- device context ----------------------------------------------
-        self.engine = _lib.Engine(cube_shape, self.fsf.shape, device=device)
-        self.engine.set_taps(self.fsf, self.lsf)
-        self.engine.set_data(self.cube.data, self.variance_cube, mask=self.mask)
+        self.engines = []
+        for r in range(n_chains):
+            eng = _lib.Engine(cube_shape, self.fsf.shape, device=device)
+            self.engines.append(eng)
+            eng.set_taps(self.fsf, self.lsf)
+            eng.set_data(self.cube.data, self.variance_cube, mask=self.mask)
+        self.engine = self.engines[0]
         host_chain = None
+        if self._host_model and n_chains > 1:
+            raise NotImplementedError("chains= needs a line model evaluated on the device "
+                                      "(SingleGaussianLineModel); %s runs on the host"
+                                      % type(self.model).__name__)
         if self._host_model:
             from .host_model import HostModelChain
             self.logger.info("Line model %s is evaluated on the host (slower path)."
@@ -257,10 +299,11 @@ class Run:
                                         self.seed, refresh_every)
             self._host_chain = host_chain
         else:
-            self.engine.set_params(self.chain[0])
-            self.engine.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
-                                  gibbs_apriori_variance, seed=self.seed,
-                                  refresh_every=refresh_every)
+            for r, eng in enumerate(self.engines):
+                eng.set_params(self.chains[r][0])
+                eng.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
+                              gibbs_apriori_variance, seed=self.seed + r,
+                              refresh_every=refresh_every)
         # a resumed run continues the checkpointed run's sweep numbering: sweep s of
         # this segment draws the random numbers of sweep s + origin
         self.sweep_origin = 0
@@ -282,16 +325,20 @@ class Run:
                 host_chain.set_sweep_origin(self.sweep_origin)
         self.logger.info("Iteration #1")
         if host_chain is None:
-            self.engine.residual(fetch=False)          # lib/run.py:317-334
+            for eng in self.engines:
+                eng.residual(fetch=False)              # lib/run.py:317-334
 
         # ---- MH within Gibbs loop (lib/run.py:336-537) -------------------------
         cur_iteration = 1
         cur_acceptance_rate = 0.
-        accepted_count = spaxels_count             # first iteration counts as accepted
+        accepted_count = spaxels_count * n_chains  # first iteration counts as accepted
+        per_chain_accepted = [spaxels_count] * n_chains
         # (accepted, iterations) of earlier segments: the running acceptance rate of the
         # stopping rule (lib/run.py:344-359) is that of the WHOLE chain.  This segment's
         # iteration 1 is the resumed state itself, already counted there.
         self._resumed_from = resumed_accepted
+        import time as _time
+        self.mh_seconds = 0.0                      # wall time of the device calls of the loop
         self._acc_base = resumed_accepted[0] - spaxels_count if resumed_accepted else 0
         self._it_base = resumed_accepted[1] - 1 if resumed_accepted else 0
         # the reference re-evaluates the stopping rule (and logs) every sweep
@@ -305,7 +352,7 @@ class Run:
         self.iterations_done = 1
         while cur_iteration < max_iterations and \
                 (cur_acceptance_rate > min_acceptance_rate or cur_acceptance_rate == 0.):
-            max_accepted_count = spaxels_count * (cur_iteration + self._it_base)
+            max_accepted_count = spaxels_count * n_chains * (cur_iteration + self._it_base)
             if max_accepted_count > 0:
                 cur_acceptance_rate = float(accepted_count + self._acc_base) / float(max_accepted_count)
             n = min(sweeps_per_call, max_iterations - cur_iteration)
@@ -318,9 +365,17 @@ class Run:
                                                    likelihoods[slot] if save else None)
                 if save:
                     self.chain[slot] = host_chain.params
-            else:
+            elif n_chains == 1:
+                t_call = _time.perf_counter()
                 accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
                                                         self.chain, likelihoods)
+                self.mh_seconds += _time.perf_counter() - t_call
+            else:
+                t_call = _time.perf_counter()
+                acc = self._sweep_chains(n, cur_iteration, all_likelihoods)
+                self.mh_seconds += _time.perf_counter() - t_call
+                accepted_count += sum(acc)
+                per_chain_accepted = [a + b for a, b in zip(per_chain_accepted, acc)]
             before = cur_iteration
             cur_iteration += n
             # write_every: documented (lib/run.py:89-92) but never used by the
@@ -330,16 +385,24 @@ class Run:
                 self._write_checkpoint(checkpoint, cur_iteration, accepted_count)
         self.iterations_done = cur_iteration
         self.acceptance_rate = float(accepted_count + self._acc_base) / \
-            float(max(spaxels_count * (cur_iteration + self._it_base), 1))
+            float(max(spaxels_count * n_chains * (cur_iteration + self._it_base), 1))
+        if n_chains > 1:
+            self.acceptance_rates = [a / float(max(spaxels_count * cur_iteration, 1))
+                                     for a in per_chain_accepted]
+        else:
+            self.acceptance_rates = [self.acceptance_rate]
         if chain_file is not None:
             n_valid = (cur_iteration - 1) // self.keep_one_in + 1
-            self.chain[n_valid:] = np.nan
-            likelihoods[n_valid:] = np.nan
-            self.chain.flush()
-            likelihoods.flush()
+            for ch, lk in zip(self.chains, all_likelihoods):
+                ch[n_valid:] = np.nan
+                lk[n_valid:] = np.nan
+                ch.flush()
+                lk.flush()
 
         # ---- outputs (lib/run.py:539-549) ------------------------------------
         self.likelihoods = likelihoods
+        self.all_likelihoods = all_likelihoods
+        self.rhat = self.gelman_rubin() if n_chains > 1 else None
         self.parameters = self.extract_parameters()
         self.convolved_cube = Cube(data=self.simulate_convolved(cube_shape, self.parameters),
                                    meta=self.cube.meta, x=cube.x, y=cube.y, z=cube.z)
@@ -361,6 +424,42 @@ class Run:
                 and type(m).post_jump is LineModel.post_jump
                 and m.gibbs_parameter_index() == 0
                 and len(m.parameters()) == 3)
+
+    def _sweep_chains(self, n, first, all_likelihoods):
+        """n sweeps of every chain: ONE launch per colour class for all of them where the
+        library can (d3d_mh_sweeps_batch: cubes up to 256 channels -- a small cube's launch
+        carries R times the windows for about the same latency), else the chains' own
+        launches on their own streams, enqueued concurrently (ensemble.sweep_chains)."""
+        from . import ensemble
+        if getattr(self, "_batched", True):
+            try:
+                acc = ensemble.sweep_chains_batched(self.engines, n, first, self.keep_one_in,
+                                                    self.chains, all_likelihoods)
+                self._batched = True
+                return acc
+            except NotImplementedError as exc:
+                self.logger.info("chains advance on their own streams (%s)" % exc)
+                self._batched = False
+        return ensemble.sweep_chains(self.engines, n, first, self.keep_one_in, self.chains,
+                                     all_likelihoods)
+
+    def gelman_rubin(self, percentage=50.):
+        """Per-parameter potential scale reduction R-hat (Gelman & Rubin 1992) over the last
+        ``percentage`` % of the saved samples of the ``chains=R`` chains, shape (H, W, P):
+        sqrt(((n-1)/n W + B/n) / W), W the mean within-chain variance and B/n the variance of
+        the chain means.  NaN where a parameter did not move (masked spaxels)."""
+        if self.n_chains < 2:
+            raise ValueError("R-hat needs chains >= 2")
+        n_valid = min((self.iterations_done - 1) // self.keep_one_in + 1, self.chain.shape[0])
+        if n_valid < 2:                          # (a variance needs two saved samples)
+            return np.full(self.chain.shape[1:], np.nan)
+        first = min(int((100. - percentage) * n_valid / 100.), n_valid - 2)
+        tail = np.stack([np.asarray(ch[first:n_valid]) for ch in self.chains])   # (R, n, H, W, P)
+        n = tail.shape[1]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            within = tail.var(axis=1, ddof=1).mean(axis=0)
+            between = tail.mean(axis=1).var(axis=0, ddof=1)
+            return np.sqrt(((n - 1.) / n * within + between) / within)
 
     def _write_checkpoint(self, name, iteration, accepted_count):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
@@ -410,12 +509,15 @@ class Run:
         return parameters + amplitude * np.tan(u)
 
     def extract_parameters(self, percentage=20.):
-        """Mean of the last ``percentage`` % of the saved chain
-        (lib/run.py:581-593); slots never written (early stop) are ignored."""
+        """Mean of the last ``percentage`` % of the saved chain -- of every chain with
+        ``chains=R`` -- (lib/run.py:581-593); slots never written (early stop) are ignored."""
         n_valid = (self.iterations_done - 1) // self.keep_one_in + 1
-        saved = self.chain[:max(1, min(n_valid, self.chain.shape[0]))]
-        s = (100. - percentage) * saved.shape[0] / 100.
-        return np.nanmean(saved[int(s):, ...], 0)
+        n_valid = max(1, min(n_valid, self.chain.shape[0]))
+        s = int((100. - percentage) * n_valid / 100.)
+        if self.n_chains == 1:
+            return np.nanmean(self.chain[s:n_valid, ...], 0)
+        # chains=R: the chains are pooled (equal lengths: the mean of their means)
+        return np.nanmean(np.stack([np.nanmean(ch[s:n_valid, ...], 0) for ch in self.chains]), 0)
 
     # SIMULATOR ###############################################################
 

@@ -36,14 +36,15 @@ one-GPU rehearsal and the bit-identity tests); host-staged torch.distributed
 
 What this buys -- measured, DESIGN.md section 7: the colour classes of a part are a
 dependent chain of fh*fw launches, and a launch that does not fill the chip costs
-~14 us at 128 channels however few windows it holds (eleven streaming wavefronts per
-window, k_mh_ws<704>; 17 us with four).  One interior rank of an 8 x 1 tiling of
-300x300x128 computes 3.5 ms per sweep alone against 4.9 ms for the whole cube on one
-GPU: the tiled chain is the mode for a cube or a chain that must be SPLIT
-(or one much larger than 300x300: at 900x900x128 a rank of 8 x 1 computes 7.2 ms against
-45.7 ms for the whole cube, 6.3x); it does not make a 300x300 chain faster.  Row
-strips (N x 1: two phases) are the default layout; 2-D grids (four phases) are
-supported and exact.  The throughput mode across GPUs is the ensemble.
+~12 us at 128 channels however few windows it holds (k_mh_small, round 4; 14 us in
+round 3).  A sweep's compute time is the sum over the PHASES of the slowest rank in each
+(`critical_path`): with 121 launches per phase and part that is >= 121 x 12 us x phases --
+2.9 ms for row strips (two phases), ~5.8 ms for a 2-D grid (four) -- against 4.9 ms for the
+whole 300x300x128 cube on one GPU.  The tiled chain is the mode for a cube or a chain that
+must be SPLIT, or one much larger than 300x300, where every part fills a chip; it does not
+make a 300x300 chain much faster.  Row strips (N x 1: two phases) are the default layout;
+2-D grids (four phases) are supported and exact.  The throughput mode across GPUs is the
+ensemble.
 
 Engines are duck-typed (`mh_phase`, `halo_pack/unpack`, `halo_download/upload`,
 ...): the product engine is `_lib.Engine`; the CPU tests drive the same code with
@@ -362,6 +363,48 @@ def parse_tiles(text, world):
     return ty, tx
 
 
+def rank_classes(layout):
+    """Ranks grouped by what they compute: {((phase, rows, columns), ...): [ranks]}.  Ranks of
+    one class run the same launches (up to where the cube's edge clips their windows)."""
+    out = {}
+    for rank in range(layout.n):
+        key = tuple((ph, r[1] - r[0], r[3] - r[2]) for ph, r in layout.parts(rank))
+        out.setdefault(key, []).append(rank)
+    return out
+
+
+def time_phases(engine, layout, rank, first_sweep, n):
+    """{phase: ms per sweep} of rank's own parts, phase by phase, alone on its GPU and without
+    halo traffic (a device synchronisation after every phase; the chain state moves on: for
+    timing only, after the chain has been used)."""
+    import time
+    mine = sorted({ph for ph, _ in layout.parts(rank)})
+    out = {ph: 0.0 for ph in mine}
+    engine.sync()
+    for s in range(first_sweep, first_sweep + n):
+        for ph in mine:
+            t0 = time.perf_counter()
+            engine.mh_phase(ph, s)
+            engine.sync()
+            out[ph] += (time.perf_counter() - t0) * 1e3 / n
+    return out
+
+
+def critical_path(phase_ms_by_rank):
+    """A tiled sweep's compute time: the phases run one after the other, all ranks at once, so
+    the sweep takes  sum over phases of the SLOWEST rank's time in that phase  (a rank without
+    a part in a phase waits).  phase_ms_by_rank: {rank: {phase: ms}}.
+    Returns (ms, {phase: (slowest rank, ms)}, rank with the largest own total)."""
+    phases = sorted({ph for t in phase_ms_by_rank.values() for ph in t})
+    per_phase = {}
+    for ph in phases:
+        rank = max(phase_ms_by_rank, key=lambda r: phase_ms_by_rank[r].get(ph, 0.0))
+        per_phase[ph] = (rank, phase_ms_by_rank[rank].get(ph, 0.0))
+    total = sum(v[1] for v in per_phase.values())
+    busiest = max(phase_ms_by_rank, key=lambda r: sum(phase_ms_by_rank[r].values()))
+    return total, per_phase, busiest
+
+
 def reference_single_context(layout, data, var, mask, fsf, lsf, init, min_b, max_b, ra, seed,
                              sweeps, device=0, refresh_every=1000):
     """The same chain on ONE context given the tiling's parts (apply_parts): what every
@@ -480,6 +523,15 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
                 bad, int(a[1].item()), int(want_acc))
             import sys
             sys.stderr.write("bench.py --mode tiled: %s\n" % sys_err)
+    # ---- the compute side of the sweep, rank by rank (the chain is not used after this) ----
+    # every rank times its own phases alone; the sweep's critical path is the sum over the
+    # phases of the slowest rank (critical_path): what the measured ms_per_step is made of
+    # beside the halo copies
+    dist.barrier()
+    my_phases = time_phases(eng, layout, rank, sweep + args.steps, 3)
+    all_phases = [None] * world
+    dist.all_gather_object(all_phases, my_phases)
+    cp_ms, cp_by_phase, busiest = critical_path(dict(enumerate(all_phases)))
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
         "unit": "spaxel-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -504,6 +556,12 @@ def bench_tiled(args, rank, local_rank, world, dist, torch):
         "max_abs_param_diff": max_diff if rank == 0 else None,
         "verified_against": "one context given the same parts (tiling.apply_parts), %d sweeps, on rank 0"
                             % (args.warmup + args.steps),
+        # sum over the phases of the slowest rank's own compute time (no halo copies): the
+        # floor of ms_per_step on this grid, and the rank whose parts make it
+        "projected_critical_path_ms": round(cp_ms, 4),
+        "slowest_rank": int(busiest),
+        "critical_path_by_phase": {str(ph): {"rank": int(r), "ms": round(ms, 4)}
+                                   for ph, (r, ms) in cp_by_phase.items()},
     }
     if rccl:
         eng.comm_destroy()
@@ -560,10 +618,21 @@ def bench_tiled_loopback(args, device):
     want, _ = reference_single_context(layout, data, var, mask, fsf, lsf, init, min_b, max_b, ra,
                                        12345, args.warmup + args.steps, device=device,
                                        refresh_every=0)
+    # what each tile would compute per sweep alone on a GPU, phase by phase, and the critical
+    # path of the grid (one representative of every class of ranks is timed)
+    timed = {}
+    for ranks in rank_classes(layout).values():
+        t = time_phases(engines[ranks[0]], layout, ranks[0], sweep, 3)
+        for r in ranks:
+            timed[r] = t
+    cp_ms, cp_by_phase, busiest = critical_path(timed)
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)", "value": round(args.steps * H * W / dt, 1),
         "unit": "spaxel-updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "tiles": [ty, tx], "phases_per_sweep": len(layout.phases), "rccl_ranks": None,
+        "projected_critical_path_ms": round(cp_ms, 4), "slowest_rank": int(busiest),
+        "critical_path_by_phase": {str(ph): {"rank": int(r), "ms": round(ms, 4)}
+                                   for ph, (r, ms) in cp_by_phase.items()},
         "bit_identical": bool(np.array_equal(got, want)),
         "max_abs_param_diff": float(np.nanmax(np.abs(got - want))),
         "ms_per_step": round(dt * 1e3 / args.steps, 4), "higher_is_better": True,

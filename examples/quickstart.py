@@ -3,7 +3,7 @@
 """
 Quick start: deconvolve a synthetic MUSE-like cube on one MI355X.
 
-    python examples/quickstart.py [iterations]
+    python examples/quickstart.py [iterations] [chains]
 
 Builds a 64x64x64 cube of one Gaussian emission line per spaxel (a rotating
 disc seen through the default MUSE instrument: Gaussian FSF, Gaussian LSF),
@@ -65,3 +65,30 @@ bright = truth[..., 0] > 3.0
 print("bright spaxels (%d): median |centre - truth| = %.2f channels, |width - truth| = %.2f channels" % (
     bright.sum(), np.median(np.abs(post[..., 1] - truth[..., 1])[bright]),
     np.median(np.abs(post[..., 2] - truth[..., 2])[bright])))
+
+
+# ---- several chains at once: chains=R ----------------------------------------------------------
+# The reference's own science fixture (tests/input/data14forAntoine.mat: 24 x 30 spaxels x 21
+# channels, settings of its tests/read_mat.py:94-121).  A colour launch of so small a cube holds
+# two or three windows -- a single chain is a chain of launch latencies -- so R independent chains
+# (seeds seed + r) advance TOGETHER, one launch per colour class for all of them, in about the
+# time of one; run.chains[r] is bit for bit the chain of Run(..., seed=seed + r), the posterior
+# means pool the chains and run.rhat says whether they agree.
+from deconv3d_amd import above_percentile  # noqa: E402
+
+chains = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                       "ref_mat_fixture.npz")
+g = np.load(fixture)
+inst2 = MUSE(fsf_fwhm=0.8841, lsf_fwhm=0.)
+cube2 = inst2.build_cube(g["data"])
+kw = dict(variance=g["var"], gibbs_apriori_variance=5., mask=above_percentile(cube2, 60),
+          max_iterations=min(iterations, 4000), keep_one_in=10, seed=7, min_acceptance_rate=0.)
+one = Run(cube2, inst2, **kw)
+many = Run(cube2, inst2, chains=chains, **kw)
+live = many.mask == 1
+print("reference fixture %s: 1 chain %.2f s of sweeps, %d chains %.2f s (%.1fx the samples per second); "
+      "chain 0 identical: %s; R-hat of the live spaxels' (a, c, w): median %s, 95th percentile %s" % (
+          "x".join(str(v) for v in g["data"].shape), one.mh_seconds, chains, many.mh_seconds,
+          chains * one.mh_seconds / many.mh_seconds, bool(np.array_equal(one.chain, many.chains[0])),
+          np.round(np.nanmedian(many.rhat[live], axis=0), 3), np.round(np.nanpercentile(many.rhat[live], 95, axis=0), 3)))

@@ -313,6 +313,44 @@ def test_run_is_reproducible_and_seed_sensitive():
     assert not np.array_equal(a.chain, c.chain)
 
 
+@pytest.mark.parametrize("batched", [True, False])
+def test_run_chains_are_the_single_runs_of_their_seeds(batched, tmp_path):
+    """Run(..., chains=R) (round 4): R independent chains of one cube advanced together --
+    one launch per colour class for all of them (d3d_mh_sweeps_batch), or, where the library
+    cannot batch, concurrently on their own streams.  Chain r IS the chain of
+    Run(..., seed=seed + r): same start, same samples, same log ratios, bit for bit;
+    extract_parameters pools the chains; rhat is the per-parameter Gelman-Rubin map."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=3)
+    kw = dict(variance=var, max_iterations=13, keep_one_in=2, min_acceptance_rate=0.)
+
+    class Threads(d3d.Run):
+        _batched = False                      # (forces ensemble.sweep_chains)
+
+    cls = d3d.Run if batched else Threads
+    multi = cls(cube, inst, seed=11, chains=3, chain_file=str(tmp_path / "m") if batched else None, **kw)
+    assert multi.n_chains == 3 and len(multi.chains) == 3 and multi.chain is multi.chains[0]
+    means = []
+    for r in range(3):
+        one = d3d.Run(cube, inst, seed=11 + r, **kw)
+        np.testing.assert_array_equal(multi.chains[r], one.chain)
+        np.testing.assert_array_equal(multi.all_likelihoods[r][1:], one.likelihoods[1:])
+        assert multi.acceptance_rates[r] == one.acceptance_rate
+        means.append(one.extract_parameters())
+    np.testing.assert_allclose(multi.parameters, np.mean(means, axis=0), rtol=1e-14)
+    assert not np.array_equal(multi.chains[0][-1], multi.chains[1][-1])
+    assert multi.rhat.shape == (9, 9, 3) and np.all(multi.rhat[np.isfinite(multi.rhat)] > 0.5)
+    assert abs(multi.acceptance_rate - np.mean(multi.acceptance_rates)) < 1e-12
+    if batched:                               # chain r > 0 of a memory-mapped run: <prefix>_c<r>_*
+        np.testing.assert_array_equal(np.load(str(tmp_path / "m_c2_chain.npy")), multi.chains[2])
+    # one start map per chain
+    starts = np.stack([multi.chains[r][3] for r in range(3)])
+    again = d3d.Run(cube, inst, seed=5, chains=3, initial_parameters=starts, **kw)
+    for r in range(3):
+        np.testing.assert_array_equal(again.chains[r][0], starts[r])
+    with pytest.raises(ValueError, match="one map per chain"):
+        d3d.Run(cube, inst, seed=5, chains=2, initial_parameters=starts, **kw)
+
+
 def test_run_initial_parameters_and_mask(tmp_path):
     """lib/run.py:294-307 (3-D, 1-D broadcast, .npy path) and masks: masked
     spaxels keep their parameters and contribute nothing (lib/run.py:553-566)."""

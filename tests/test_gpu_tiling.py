@@ -360,6 +360,11 @@ def test_bench_two_ranks_report_the_tiled_leg():
     assert leg["tiles"] == [2, 1] and leg["phases_per_sweep"] == 2
     assert leg["rccl_ranks"] is None            # gloo rehearsal: no RCCL communicator
     assert leg["halo_ms_per_sweep"] > 0.0
+    # the compute side, rank by rank: sum over the two phases of the slowest rank's own time --
+    # a floor of the measured sweep (here both ranks share one GPU, so it is well below it)
+    assert leg["slowest_rank"] in (0, 1)
+    assert 0.0 < leg["projected_critical_path_ms"] <= leg["ms_per_step"]
+    assert sorted(leg["critical_path_by_phase"]) == ["0", "2"]
 
 
 def test_a_larger_halo_plan_after_a_streamed_chain_leaves_the_streaming_buffers_alone():

@@ -250,6 +250,13 @@ def test_run_rejects_bad_inputs_like_the_reference():
         d3d.Run(cube, inst, model=Inverted)
     with pytest.raises(ValueError, match="Initial params"): # lib/run.py:300-305
         d3d.Run(cube, inst, initial_parameters=np.zeros((3, 3, 3)))
+    # chains= (additive, like seed=): a positive integer; checkpoints take one chain
+    with pytest.raises(AssertionError, match="chains"):
+        d3d.Run(cube, inst, chains=0)
+    with pytest.raises(NotImplementedError, match="one chain"):
+        d3d.Run(cube, inst, chains=2, checkpoint="x")
+    with pytest.raises(ValueError, match="one map per chain"):
+        d3d.Run(cube, inst, chains=2, initial_parameters=np.zeros((3, 9, 9, 3)))
 
 
 

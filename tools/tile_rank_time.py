@@ -1,8 +1,14 @@
-"""What ONE rank of a tiled chain computes per sweep, measured alone on one GPU (its phases
-back to back, no halo traffic), beside the whole cube's sweep on the same GPU in the same
-run: the compute side of the strong-scaling projection of DESIGN.md section 7.
+"""The compute side of a tiled chain's strong scaling, measured on ONE GPU.
 
     python tools/tile_rank_time.py [--hw 300x300] [--depth 128] [TYxTX ...]
+
+A tiled sweep runs its phases one after the other, every rank at once: its compute time is the
+CRITICAL PATH  sum over the phases of the slowest rank in that phase  (tiling.critical_path).
+So ONE representative of every class of ranks (tiling.rank_classes: same parts, same launches)
+is built as a tile context and each of its phases timed alone on the GPU -- no halo traffic --
+beside the whole cube's sweep on the same GPU in the same run.  Printed per layout: every
+class's phases, the critical path, the rank and phase it comes from, and whole cube / critical
+path = the speed-up the grid can reach before its halo copies.
 """
 import argparse
 import os
@@ -43,29 +49,30 @@ with _lib.Engine((D, H, W), fsf.shape) as full:
 print("%dx%dx%d, one GPU, whole cube: %.3f ms per sweep (%.2f M spaxel-updates/s)"
       % (H, W, D, one, H * W / one / 1e3), flush=True)
 
+NAMES = "FF FN NF NN".split()
 mask = np.ones((H, W))
 for spec in args.layouts:
     ty, tx = [int(v) for v in spec.split("x")]
     lay = tiling.TileLayout(H, W, fs, fs, ty, tx)
-    rank = (ty // 2) * tx + tx // 2 if ty * tx > 2 else 0          # an interior rank where there is one
-    eng = tiling.make_tile_engine(lay, rank, data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra,
-                                  12345)
-    for s in range(1, 3):
-        for ph in lay.phases:
-            eng.mh_phase(ph, s)
-    eng.sync()
-    t0 = time.perf_counter()
-    for s in range(3, 3 + n):
-        for ph in lay.phases:
-            eng.mh_phase(ph, s)
-    eng.sync()
-    ms = (time.perf_counter() - t0) * 1e3 / n
-    parts = ", ".join("%s %dx%d" % ("FF FN NF NN".split()[ph], r[1] - r[0], r[3] - r[2])
-                      for ph, r in lay.parts(rank))
-    halo = sum(int((r[3] - r[2]) * (r[5] - r[4])) for ph in lay.phases
-               for r in tiling.plan_tables(lay, rank)[ph]) * D * 8
-    # one xGMI link per neighbour, ~50 GB/s effective for a 3 MB message each way
-    print("%s rank %d: %.3f ms per sweep alone (parts: %s; sends %.1f MB per sweep) -> %.2fx of the "
-          "whole cube's %.2f ms before halo time" % (spec, rank, ms, parts, halo / 1e6, one / ms, one),
-          flush=True)
-    eng.close()
+    timed = {}
+    print("%s (%d ranks, phases %s):" % (spec, lay.n, " ".join(NAMES[p] for p in lay.phases)), flush=True)
+    for key, ranks in tiling.rank_classes(lay).items():
+        rank = ranks[len(ranks) // 2]
+        eng = tiling.make_tile_engine(lay, rank, data, var, mask, fsf, lsf, init, min_b, max_b, 0.1, ra,
+                                      12345)
+        tiling.time_phases(eng, lay, rank, 1, 2)               # warm
+        t = tiling.time_phases(eng, lay, rank, 3, n)
+        eng.close()
+        for r in ranks:
+            timed[r] = t
+        halo = sum(int((r[3] - r[2]) * (r[5] - r[4])) for ph in lay.phases
+                   for r in tiling.plan_tables(lay, rank)[ph]) * D * 8
+        print("   ranks %-14s %s  = %.3f ms alone; sends %.1f MB per sweep"
+              % (",".join(str(r) for r in ranks),
+                 "  ".join("%s %dx%d %.3f ms" % (NAMES[ph], hh, ww, t[ph]) for ph, hh, ww in key),
+                 sum(t.values()), halo / 1e6), flush=True)
+    cp, by_phase, busiest = tiling.critical_path(timed)
+    print("   critical path %.3f ms per sweep = %s  -> %.2fx of the whole cube's %.3f ms before halo "
+          "time (busiest rank %d: %.3f ms)"
+          % (cp, " + ".join("%s %.3f (rank %d)" % (NAMES[ph], ms, r) for ph, (r, ms) in by_phase.items()),
+             one / cp, one, busiest, sum(timed[busiest].values())), flush=True)
