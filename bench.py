@@ -27,6 +27,8 @@ Prints ONE JSON line (rank 0).  Besides the contract keys it carries
                           (one workgroup per window and 256-channel block + a decision launch)
   chains_batched       -- config 2's cube as 16 independent chains in one launch per colour class
   roofline_conv        -- the separable LSF (x) FSF convolution of one cube
+  roofline_forward     -- parameters -> convolved cube (line build + convolution)
+  roofline_chi2        -- the per-spaxel chi2 reduction of the residual
   cpu_baseline         -- the oracle's memory-sane numpy update loop on the host cores
   cpu_baseline_conv    -- the oracle's LSF (x) FSF convolution of one cube on the host
   host                 -- CPU model string and core counts of the box
@@ -685,6 +687,41 @@ def main():
     roofline_conv_ref_layout = conv_entry(stage_ms, "k_spectral_z + k_spatial_z (reference layout)",
                                           "k_spatial_z")
 
+    # ---- the other two things north_star names, priced with SURVEY 8(d)'s bytes ----
+    # forward model (lib/run.py:1011-1029): parameters -> convolved cube = k_lines (raw lines,
+    # one exp per voxel) + k_conv_rows (FSF, LSF in its epilogue): H W 3 8 + D H W 8 algorithmic
+    # bytes; the 92 MB line cube between the two launches is traffic, not algorithm.
+    # chi2 map (lib/run.py:423-424): 0.5 sum_z err^2 / var per spaxel from the CARRIED residual
+    # and 1/var (2 D H W 8 + H W 8 bytes; SURVEY's 276.5 MB is the three-cube form data, sim, var).
+    eng.forward(fetch=False)
+    eng.sync()
+    eng.timer_start()
+    for _ in range(args.conv_iters):
+        eng.forward(fetch=False)
+    fwd_ms = eng.timer_stop() / max(args.conv_iters, 1)
+    fwd_bytes = H * W * 3 * 8 + D * H * W * 8
+    fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+    roofline_forward = {"kernel": "k_lines + k_conv_rows (parameters -> convolved cube, two launches)",
+                        "bound": "hbm", "achieved": round(fwd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(fwd_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": fwd_bytes,
+                        "ms_per_forward": round(fwd_ms, 4),
+                        "ms_line_build": round(fwd_ms - slots_ms, 4),
+                        "traffic": measured_traffic("k_lines<256>", args.workload)}
+    eng.chi2_map(fetch=False)
+    eng.sync()
+    eng.timer_start()
+    for _ in range(args.conv_iters):
+        eng.chi2_map(fetch=False)
+    chi_ms = eng.timer_stop() / max(args.conv_iters, 1)
+    chi_bytes = 2 * D * H * W * 8 + H * W * 8
+    chi_gbs = chi_bytes / (chi_ms * 1e-3) / 1e9
+    roofline_chi2 = {"kernel": "k_chi2_map (carried residual, 1/var -> per-spaxel 0.5 chi2)", "bound": "hbm",
+                     "achieved": round(chi_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(chi_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": chi_bytes,
+                     "us_per_map": round(chi_ms * 1e3, 2),
+                     "traffic": measured_traffic("k_chi2_map", args.workload)}
+    traffic_rates(roofline_chi2, chi_ms * 1e3)
+
     out = {
         "metric": "spaxel-updates/sec (MH-Gibbs)",
         "value": round(value, 1),
@@ -710,6 +747,8 @@ def main():
         "roofline": roofline,
         "roofline_conv": roofline_conv,
         "roofline_conv_ref_layout": roofline_conv_ref_layout,
+        "roofline_forward": roofline_forward,
+        "roofline_chi2": roofline_chi2,
     }
 
     if rank == 0 and not args.no_extras:

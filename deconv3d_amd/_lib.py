@@ -355,7 +355,10 @@ class Engine(object):
         _check(self._lib.d3d_residual(self._ctx, _dp(out) if fetch else None))
         return out
 
-    def chi2_map(self):
+    def chi2_map(self, fetch=True):
+        if not fetch:                       # device only, no wait (timing)
+            _check(self._lib.d3d_chi2_map(self._ctx, None, None))
+            return None
         out = np.empty(self.shape[1:], dtype=np.float64)
         tot = C.c_double(0.)
         _check(self._lib.d3d_chi2_map(self._ctx, _dp(out), C.byref(tot)))

@@ -372,16 +372,22 @@ bool conv_rows_usable(const d3d_ctx *c, bool with_lsf) {
     // (the LSF epilogue is built for mirror-symmetric taps only -- every Gaussian / MUSE-like
     // LSF; an asymmetric one gets its own pass)
     if (with_lsf && !(c->ntaps > 0 && c->lsf_dense_ok && c->N == c->D && c->lsf_dense_sym)) return false;
+    // (15 x 15 -- the FSF of the reference's own science fixture, tests/read_mat.py:28-36 --
+    // keeps its taps in scalar registers only in the radial and outer-product forms: 36 / 16
+    // values; the general quadrant form would need 64)
+    const bool fs15_ok = c->fsf_symt || (c->fsf_sep && c->march_mode > 0);
     if (c->Dp == 64 || c->Dp == 32)  // several spectra per wavefront: the BASELINE footprints,
         return (c->fw == 9 || c->fw == 11) &&
                (c->fsf_symt || (c->fsf_sep && c->march_mode > 0));  // radial or outer-product FSFs
-    // every other depth above 64: z-blocks of 128 channels (the last one ragged), FSF only --
-    // the LSF couples the blocks
-    if (c->Dp > 64 && c->Dp != d3d::CONV_DP)
-        return !with_lsf && c->conv_zb && (c->fw == 9 || c->fw == 11 || c->fw == 13);
-    if (c->Dp != d3d::CONV_DP) return false;
+    // every other depth: z-blocks of 128 channels (the last -- below 128 channels the only --
+    // one ragged), FSF only: the LSF couples the blocks, and at a depth that is not a power of
+    // two it wraps partially (lib/convolution.py:123-160)
+    if (c->Dp != d3d::CONV_DP)
+        return !with_lsf && c->conv_zb &&
+               (c->fw == 9 || c->fw == 11 || c->fw == 13 || (c->fw == 15 && fs15_ok));
     switch (c->fw) {
         case 3: case 5: case 7: case 9: case 11: case 13: return true;
+        case 15: return fs15_ok;
         default: return false;
     }
 }
@@ -432,7 +438,7 @@ template <int FS, int DPS = d3d::CONV_DP>
 int launch_conv_rows_fs(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
     if (c->fsf_sep && c->march_mode > 0) return launch_conv_rows_ts<FS, 2, DPS>(c, in, out, data, lsf);
     if (c->fsf_symt) return launch_conv_rows_ts<FS, 1, DPS>(c, in, out, data, lsf);
-    if constexpr (DPS == d3d::CONV_DP) return launch_conv_rows_ts<FS, 0, DPS>(c, in, out, data, lsf);
+    if constexpr (DPS == d3d::CONV_DP && FS < 15) return launch_conv_rows_ts<FS, 0, DPS>(c, in, out, data, lsf);
     return fail(D3D_ERR_STATE, "internal: no one-pass kernel for this FSF at %d channels", c->Dp);
 }
 
@@ -446,17 +452,20 @@ int launch_conv_rows_zb(d3d_ctx *c, const double *in, double *out, const double 
     if (c->fsf_symt)
         return data ? launch_conv_rows_t<FS, false, false, true, 1, DP, true>(c, in, out, data)
                     : launch_conv_rows_t<FS, false, false, false, 1, DP, true>(c, in, out, data);
-    return data ? launch_conv_rows_t<FS, false, false, true, 0, DP, true>(c, in, out, data)
-                : launch_conv_rows_t<FS, false, false, false, 0, DP, true>(c, in, out, data);
+    if constexpr (FS < 15)
+        return data ? launch_conv_rows_t<FS, false, false, true, 0, DP, true>(c, in, out, data)
+                    : launch_conv_rows_t<FS, false, false, false, 0, DP, true>(c, in, out, data);
+    return fail(D3D_ERR_STATE, "internal: no one-pass kernel for a general 15 x 15 FSF");
 }
 
 int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *data, bool lsf) {
-    if (c->Dp > 64 && c->Dp != d3d::CONV_DP) {
+    if (c->Dp != 64 && c->Dp != 32 && c->Dp != d3d::CONV_DP) {
         if (lsf) return fail(D3D_ERR_STATE, "internal: one-pass LSF requested at %d channels", c->Dp);
         switch (c->fw) {
             case 9: return launch_conv_rows_zb<9>(c, in, out, data);
             case 11: return launch_conv_rows_zb<11>(c, in, out, data);
-            default: return launch_conv_rows_zb<13>(c, in, out, data);
+            case 13: return launch_conv_rows_zb<13>(c, in, out, data);
+            default: return launch_conv_rows_zb<15>(c, in, out, data);
         }
     }
     if (c->Dp == 64)
@@ -471,7 +480,8 @@ int launch_conv_rows(d3d_ctx *c, const double *in, double *out, const double *da
         case 7: return launch_conv_rows_fs<7>(c, in, out, data, lsf);
         case 9: return launch_conv_rows_fs<9>(c, in, out, data, lsf);
         case 11: return launch_conv_rows_fs<11>(c, in, out, data, lsf);
-        default: return launch_conv_rows_fs<13>(c, in, out, data, lsf);
+        case 13: return launch_conv_rows_fs<13>(c, in, out, data, lsf);
+        default: return launch_conv_rows_fs<15>(c, in, out, data, lsf);
     }
 }
 

@@ -144,7 +144,8 @@ int d3d_simulate(d3d_ctx *ctx, const double *params, int convolved, double *out_
  * Stored in SLOT_ERR; out_err may be NULL. */
 int d3d_residual(d3d_ctx *ctx, double *out_err);
 /* Per-spaxel 0.5*sum_z err^2/var of SLOT_ERR (the quantity of
- * lib/run.py:423 summed per spectrum) and its total.  Either may be NULL. */
+ * lib/run.py:423 summed per spectrum) and its total.  Either may be NULL; with both NULL
+ * the map stays on the device and the call returns without waiting for it. */
 int d3d_chi2_map(d3d_ctx *ctx, double *out_hw, double *total);
 
 /* The same convolution on a cube that stays on the device in the REFERENCE

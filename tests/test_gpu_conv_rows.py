@@ -65,6 +65,17 @@ CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
     (249, 4, 9, 11, "asym", None),
     (1020, 3, 4, 9, "asym", None),
     (100, 7, 6, 9, "asym", None),         # one ragged block
+    # round 4: 15 x 15 -- the footprint of the reference's own science fixture
+    # (tests/read_mat.py:28-36) -- in the radial form, with the LSF epilogue and in z-blocks
+    (128, 23, 19, 15, "muse", None),
+    (128, 9, 33, 15, "asym", 4),          # fewer rows than the FSF
+    (128, 31, 16, 15, "none", 7),
+    (256, 17, 20, 15, "muse", None),
+    # ... and depths below 128 that are no power of two: ONE ragged z-block (FSF pass only)
+    (21, 30, 24, 15, "muse", None),       # the fixture's shape
+    (30, 17, 31, 11, "asym", 5),
+    (48, 9, 16, 9, "none", None),
+    (2, 5, 7, 9, "none", None),
 ]
 
 
@@ -72,7 +83,7 @@ CASES = [  # (D, H, W, fsf size, lsf kind, strip height override)
 def test_one_pass_convolution_matches_the_oracle_and_the_two_pass_kernels(D, H, W, fs, lsf_kind, hy):
     rng = np.random.default_rng(D * 1000 + H * 31 + W)
     fsf = O.moffat_cropped(fs, 3.0, 2.5)
-    lsf = {"muse": O.muse_like_lsf(D), "asym": lsf_asym(D, rng), "none": None}[lsf_kind]
+    lsf = {"muse": O.muse_like_lsf, "asym": lambda d: lsf_asym(d, rng), "none": lambda d: None}[lsf_kind](D)
     cube = rng.normal(size=(D, H, W))
     want = O.convolve_cube(cube, fsf, lsf) if lsf is not None else O.spatial_convolve(cube, fsf)
     outs = []
@@ -162,3 +173,25 @@ def test_z_blocked_fsf_pass_for_every_symmetric_fsf_class(kind, D):
     for got in outs:
         assert np.max(np.abs(got - want)) <= 1e-12 * scale
     assert not np.array_equal(outs[0], outs[1])        # two kernels did run
+
+
+def test_reference_fixture_forward_model_runs_the_one_pass_kernel():
+    """tests/input/data14forAntoine.mat (committed as golden/ref_mat_fixture.npz): 21 channels,
+    24 x 30 spaxels, the 15 x 15 FSF of the file itself (radial to the last bit).  Round 3's
+    k_conv_rows took neither the footprint nor the depth; now the forward model of the
+    theoretical parameters (c - 1: tests/read_mat.py:49-68) equals the oracle's and is the same
+    with the one-pass kernel switched off."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_mat_fixture.npz"))
+    data, fsf, params = g["data"], np.ascontiguousarray(g["fsf"]), g["params"].copy()
+    D, H, W = data.shape
+    assert fsf.shape == (15, 15) and np.array_equal(fsf, fsf.T) and np.array_equal(fsf, fsf[::-1])
+    want = O.forward_full((D, H, W), params, np.ones((H, W)), fsf, None)
+    outs = []
+    for conv_rows in (True, False):
+        with engine((D, H, W), fsf, None, conv_rows) as eng:
+            eng.set_params(params)
+            outs.append(eng.forward())
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(outs[0] - want)) <= 1e-12 * scale
+    assert np.max(np.abs(outs[0] - outs[1])) <= 1e-13 * scale
