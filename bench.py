@@ -350,6 +350,13 @@ def fp64_rates(entry, flops, ms, shape=None, instr_per_pair_step=None, fs=11):
         entry["fp64_issue_frac"] = round(issued / (ms * 1e-3) / 1e12 / (FP64_VEC_PEAK_TF / 2.0), 4)
 
 
+def kept_lsf_taps(lsf, bound=1e-16):
+    """Taps d3d_set_taps keeps (Engine.set_taps' default: the smallest are dropped within an
+    error bound of `bound` * sum|lsf|)."""
+    mag = np.sort(np.abs(np.asarray(lsf, dtype=np.float64)))
+    return int(mag.size - np.searchsorted(np.cumsum(mag), bound * mag.sum(), side="right"))
+
+
 def traffic_rates(entry, us):
     """traffic_gbs / traffic_frac of a roofline entry whose `traffic` is a byte count."""
     if isinstance(entry.get("traffic"), int) and entry["traffic"] > 0:
@@ -464,7 +471,7 @@ def conv_beyond_mall_leg(args, local_rank, fs):
         ms = eng.timer_stop() / iters
     nbytes = 2 * 8 * D * H * W
     gbs = nbytes / (ms * 1e-3) / 1e9
-    ntaps = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
+    ntaps = kept_lsf_taps(lsf)
     flops = 2.0 * (fsf.size + ntaps) * D * H * W
     out = {"kernel": "k_conv_rows, 600x600x128 cube (369 MB in + 369 MB out > 256 MB MALL)",
            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -652,7 +659,7 @@ def main():
     # download), (b) between two spectrum-contiguous slots (the layout of the MH
     # loop, used by the forward model / residual refresh).
     conv_bytes = 2 * 8 * D * H * W                                # cube in -> cube out
-    ntaps_lsf = int(np.count_nonzero(np.abs(lsf) > 1e-20 * np.abs(lsf).max()))
+    ntaps_lsf = kept_lsf_taps(lsf)
     conv_flops = 2.0 * (fh * fw + ntaps_lsf) * D * H * W
 
     def conv_entry(ms, kernel, traffic_key, flops=conv_flops, instr=None):

@@ -292,7 +292,9 @@ class Engine(object):
         return ms.value
 
     # -- inputs -----------------------------------------------------------
-    def set_taps(self, fsf, lsf, lsf_rel_threshold=1e-20):
+    def set_taps(self, fsf, lsf, lsf_rel_threshold=-1e-16):
+        """lsf_rel_threshold < 0: taps are dropped within that error bound of sum|lsf|
+        (include/deconv3d_hip.h); >= 0: relative to the largest tap."""
         fsf = _c64(fsf, self.fsf_shape)
         lsf_p = None
         if lsf is not None:

@@ -122,9 +122,11 @@ void pick_mh_geometry(d3d_ctx *c) {
     // (mh_defer -- 0: immediate write-back, 1: deferred + wave-specialised, 2: deferred, plain)
     // measured crossover on MI355X (256 MiB Infinity Cache): 276 / 323 MB +1 %, 369 MB +6 %,
     // 230 MB -7 % (tools/mh_sizes.py)
-    // The write-through residual stores of that variant address SLOT_ERR as a raw buffer
-    // with 32-bit byte offsets: never beyond 2 GiB, whatever the option says.
-    const bool fits_raw = 8.0 * (double)c->Dp * (double)c->H * (double)c->W < 2147483648.0;
+    // The write-through residual stores of that variant address the residual through a raw
+    // buffer of the WINDOW (32-bit byte offsets from its first cell: (fh + 1) rows of the cube
+    // must span < 2 GiB -- every cube this library takes; round 3 used one buffer over the whole
+    // slot and switched the policy off for residuals >= 2 GiB, e.g. a full MUSE cube).
+    const bool fits_raw = 8.0 * (double)c->Dp * (double)(c->fh + 1) * (double)c->W < 2147483648.0;
     c->mh_nt_ivar = 16.0 * (double)c->Dp * (double)c->H * (double)c->W >= 350e6;
     if (c->mh_nt_ivar_opt >= 0) c->mh_nt_ivar = c->mh_nt_ivar_opt != 0;
     c->mh_nt_ivar = c->mh_nt_ivar && fits_raw;
@@ -243,7 +245,8 @@ int build_colour_lists(d3d_ctx *c) {
         const bool partitioned = c->tiled || !c->part_rects.empty();
         pt.wide = pt.layers == 1 && c->mh_wide && partitioned && c->Dp == 128 && most > 0 &&
                   most <= c->flow_grid / 4 && c->mh_defer == 1;
-        pt.small = pt.layers == 1 && most_wgs < c->flow_grid / 2;
+        // (option mh_small = 2, measurements only: every one-layer part, chip-filling or not)
+        pt.small = pt.layers == 1 && (most_wgs < c->flow_grid / 2 || c->mh_small == 2);
         // k_mh_chain: whole sweeps of the part in one launch of persistent workgroups, one per
         // lattice slot -- where every slot is resident at once (one workgroup per CU) and a
         // thread can hold its share of the window in registers
@@ -412,7 +415,7 @@ const OptDesc g_opts[] = {
     {"mh_layers", "D3D_MH_LAYERS", &d3d_ctx::mh_layers_opt, OPT_MH, 0, d3d::MH_LAYERS},
     {"mh_wide", "D3D_MH_WIDE", &d3d_ctx::mh_wide, OPT_MH, 0, 1},
     {"mh_props", "D3D_MH_PROPS", &d3d_ctx::mh_props, OPT_LAUNCH, 0, 1},
-    {"mh_small", "D3D_MH_SMALL", &d3d_ctx::mh_small, OPT_MH, 0, 1},
+    {"mh_small", "D3D_MH_SMALL", &d3d_ctx::mh_small, OPT_MH, 0, 2},
     {"halo_timing", "D3D_HALO_TIMING", &d3d_ctx::halo_timing, OPT_LAUNCH, 0, 1},
     {"mh_zigzag", "D3D_MH_ZIGZAG", &d3d_ctx::mh_zigzag, OPT_MH, 0, 1},
     {"mh_nt_ivar", "D3D_MH_NT_IVAR", &d3d_ctx::mh_nt_ivar_opt, OPT_MH, -1, 1},
@@ -716,6 +719,25 @@ int d3d_ctx_get_option(d3d_ctx *c, const char *key, long *value) {
         *value = c->have_data ? n : 0;
         return D3D_OK;
     }
+    // read-only, derived: what the context actually runs
+    if (!strcmp(key, "mh_nt_ivar_on")) {  // the beyond-the-Infinity-Cache policy of k_mh_ws is in effect
+        *value = c->mh_nt_ivar ? 1 : 0;
+        return D3D_OK;
+    }
+    if (!strcmp(key, "lsf_fits")) {       // the LSF taps lie within +-LSF_RL channels: fused / z-blocked kernels
+        *value = (c->have_taps && (c->ntaps == 0 || c->lsf_dense_any)) ? 1 : 0;
+        return D3D_OK;
+    }
+    if (!strcmp(key, "lsf_taps")) {
+        *value = c->ntaps;
+        return D3D_OK;
+    }
+    if (!strcmp(key, "small_parts")) {    // parts whose colour launches run k_mh_small
+        long n = 0;
+        for (const d3d_ctx::Part &pt : c->parts) n += (pt.small && d3dh::mh_small_usable(c)) ? 1 : 0;
+        *value = c->have_data ? n : 0;
+        return D3D_OK;
+    }
     const OptDesc *o = find_opt(key);
     NEED(o, D3D_ERR_INVALID, "unknown option '%s'", key);
     *value = c->*(o->field);
@@ -830,9 +852,43 @@ static int set_taps_impl(d3d_ctx *c, const double *fsf, const double *lsf, doubl
         const int N = c->N, D = c->D;
         const int diff = N - D;
         const int h = (diff & 1) ? diff / 2 + 1 : diff / 2;  // lib/convolution.py:149-153
-        double mx = 0.0;
-        for (int t = 0; t < D; ++t) mx = std::fmax(mx, std::fabs(lsf[t]));
-        const double cut = thr * mx;
+        double mx = 0.0, total = 0.0;
+        for (int t = 0; t < D; ++t) {
+            mx = std::fmax(mx, std::fabs(lsf[t]));
+            total += std::fabs(lsf[t]);
+        }
+        // thr >= 0: taps up to thr * max|lsf| are dropped.  thr < 0 (round 4, the python host's
+        // default -1e-16): an ERROR BOUND -- the smallest taps are dropped as long as their summed
+        // magnitude stays within |thr| * sum|lsf|, i.e. below the rounding of the fp64 sum itself.
+        // (Round 3's 1e-20 * max kept a Gaussian's tail out to 9.6 sigma, and the physics-free
+        // threshold, not the LSF, decided whether the taps fit the +-LSF_RL channels of the fused /
+        // z-blocked kernels: sigma >= 0.94 px fell off them.  The bound keeps 8.6 sigma: MUSE's
+        // 2.4-3.0 A LSF at 1.25 A per channel, sigma 0.82-1.02 px, fits.)
+        double cut = thr * mx;
+        if (thr < 0.0) {
+            std::vector<double> mag(lsf, lsf + D);
+            for (double &m : mag) m = std::fabs(m);
+            std::sort(mag.begin(), mag.end());
+            double dropped = 0.0;
+            cut = 0.0;
+            for (int t = 0; t < D && dropped + mag[t] <= -thr * total; ++t) {
+                dropped += mag[t];
+                cut = mag[t];
+            }
+            // (taps EQUAL to the largest dropped magnitude: keep the bound -- drop them only if all fit)
+            double at_cut = 0.0;
+            for (int t = 0; t < D; ++t)
+                if (std::fabs(lsf[t]) <= cut) at_cut += std::fabs(lsf[t]);
+            while (at_cut > -thr * total && cut > 0.0) {   // shrink to the next smaller magnitude
+                double next = 0.0;
+                for (int t = 0; t < D; ++t)
+                    if (mag[t] < cut) next = std::fmax(next, mag[t]);
+                cut = next;
+                at_cut = 0.0;
+                for (int t = 0; t < D; ++t)
+                    if (std::fabs(lsf[t]) <= cut) at_cut += std::fabs(lsf[t]);
+            }
+        }
         for (int t = 0; t < D; ++t) {
             if (!(std::fabs(lsf[t]) > cut)) continue;
             int s = (N / 2 - h - t) % N;

@@ -2594,13 +2594,23 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
             // the padding channel of an odd depth carries 1/var = 0
             const double2 vu = make_double2(P.ivar_uniform,
                                             (2 * zl + 1 < P.D) ? P.ivar_uniform : 0.0);
-            // raw buffer over SLOT_ERR (the launcher checks that it is < 2 GiB); aux 16 = sc1
+            // raw buffer over SLOT_ERR; aux 16 = sc1.  COH (k_mh_flow / k_mh_pair, loads and
+            // stores): the whole slot, which the launcher checks to be < 2 GiB.  NTV alone
+            // (write-through STORES of a context beyond the Infinity Cache): a buffer of this
+            // WINDOW -- base = its first cell, 32-bit offsets within (fh + 1) rows of the cube --
+            // so that the policy survives residual cubes of any size (round 4: a full MUSE cube,
+            // 300x300x3682, is 2.65 GB)
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             union { double2 d; v4u i; } cv;
+            long rs_vox = 0;   // first cell the buffer covers
+            if constexpr (NTV && !COH) {
+                const int fhh_ = (P.fh - 1) / 2, fhw_ = (P.fw - 1) / 2;
+                rs_vox = max(0L, (long)(I.y - fhh_) * P.W + (I.x - fhw_));
+            }
+            const long rs_bytes =
+                (COH || NTV) ? ((long)P.H * P.W - rs_vox) * zstride * 8 - (ZBK ? Zp->z0 : 0) * 8 : 0;
             const __amdgpu_buffer_rsrc_t err_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                P.err, 0,
-                (COH || NTV) ? (int)(((long)P.H * P.W * zstride - (ZBK ? Zp->z0 : 0)) * 8) : 0,
-                0x00020000);
+                P.err + rs_vox * zstride, 0, (int)(unsigned)min(rs_bytes, 0x7fffffffL), 0x00020000);
             // U window positions per round: all their loads are issued before the
             // first is consumed.  U = 1 when a launch fills the chip (the stream is at
             // the HBM peak; more requests in flight only add contention: 52.9 vs
@@ -2664,8 +2674,8 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
                         // 79.4 -> 76.7 us per launch, nothing where everything fits)
                         if (COH || NTV) {
                             cv.d = e[u];
-                            __builtin_amdgcn_raw_buffer_store_b128(cv.i, err_rsrc, (int)(idx * 8), 0,
-                                                                   16);
+                            __builtin_amdgcn_raw_buffer_store_b128(
+                                cv.i, err_rsrc, (int)((idx - rs_vox * zstride) * 8), 0, 16);
                         } else {
                             *reinterpret_cast<double2 *>(P.err + idx) = e[u];
                         }
@@ -2769,6 +2779,11 @@ __device__ __forceinline__ void mh_ws_run(const MHArgs &P, const MHShared &S, co
         return;
     }
     double Gt;
+    // (Round 4, measured and dropped HERE: k_mh_small's tail -- the decision on every wavefront
+    // that holds channels, one barrier instead of two -- 40.7 -> 41.5 us per launch at
+    // 300x300x128, 31.4 -> 32.1 with uniform variance, same-box A/B, whether or not the other
+    // wavefronts end early: with three workgroups per compute unit a second deciding wavefront
+    // per window takes issue slots from the neighbours' window passes.  ONE wavefront decides.)
     if (!mh_finish(P, S, q, sp, sweep, tid, G, EO, EN, 0, NS / 64, streamer, &Gt, &u_gibbs, stamp_at))
         return;
     if (tid < Dp) {

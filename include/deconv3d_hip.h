@@ -110,7 +110,10 @@ int d3d_has_experiments(void);
 /* Taps produced once per run by instrument.fsf.as_image / lsf.as_vector,
  * lib/run.py:207-211.  lsf may be NULL (no spectral pass: lib/run.py:675-676,
  * 1015-1016).  LSF taps with |lsf[t]| <= lsf_rel_threshold*max|lsf| are
- * dropped (0 keeps every non-zero tap; the python host uses 1e-20). */
+ * dropped (0 keeps every non-zero tap).  A NEGATIVE value is an error bound: the
+ * smallest taps are dropped while their summed magnitude stays within
+ * |lsf_rel_threshold| * sum|lsf| (the python host uses -1e-16: below the rounding of
+ * the fp64 sum). */
 int d3d_set_taps(d3d_ctx *ctx, const double *fsf, const double *lsf,
                  double lsf_rel_threshold);
 /* Data / variance / mask setup of lib/run.py:137-200.  var may be NULL (then

@@ -30,7 +30,8 @@ def small_problem(D, H, W, fsf, lsf, seed=0):
 
 @pytest.mark.parametrize("D,lsf_kind", [(d, "gauss") for d in (100, 128, 200, 256, 257, 300, 512, 513, 1000,
                                                                  1024, 1025, 2048, 3700)] +
-                         [(d, "muse") for d in (513, 770, 1024, 1025, 2048, 3700)])
+                         [(d, "muse") for d in (513, 770, 1024, 1025, 2048, 3700)] +
+                         [(d, "gauss1.0") for d in (128, 600, 1500)])
 def test_deep_cubes_chain_matches_oracle(D, lsf_kind):
     """Depths that select every MH kernel: wave-specialised with 256 (D <= 256) or 512
     streaming threads (D <= 512), plain deferred beyond, 256/512/1024-thread blocks, the z-blocked forms beyond 1024
@@ -38,14 +39,22 @@ def test_deep_cubes_chain_matches_oracle(D, lsf_kind):
     and non-power-of-two depths with the partial-wrap LSF.  "muse": LSF taps within +-8
     channels -- beyond 512 channels the z-blocked form of the wave-specialised kernel
     (k_mh_ws on 256-channel blocks + k_mh_zdecide); "gauss": a Gaussian's long tail of tiny
-    taps -- the plain deferred / thread-looped kernels there."""
+    taps -- the plain deferred / thread-looped kernels there.  "gauss1.0" (round 4): a Gaussian
+    LSF of sigma 1.0 px, FWHM 2.94 A at MUSE's 1.25 A per channel -- the upper end of the
+    instrument's range.  Its taps fit the +-8 channels of the fused and z-blocked kernels once
+    the cut is an error bound of the sum (1e-16) instead of 1e-20 of the largest tap."""
     H, W = 5, 6
     fsf = O.gaussian_fsf_image(1.6)
-    lsf = O.gaussian_lsf_vector(D, 1.1) if lsf_kind == "gauss" else O.muse_like_lsf(D)
+    lsf = {"gauss": lambda d: O.gaussian_lsf_vector(d, 1.1), "gauss1.0": lambda d: O.gaussian_lsf_vector(d, 1.0),
+           "muse": O.muse_like_lsf}[lsf_kind](D)
     data, var, mask, truth, init, min_b, max_b = small_problem(D, H, W, fsf, lsf, seed=D)
     st = O.MHState(data, var, mask, fsf, lsf, init, min_b, max_b, seed=3)
     with _lib.Engine((D, H, W), fsf.shape) as eng:
+        if lsf_kind == "gauss1.0":
+            eng.set_taps(fsf, lsf, lsf_rel_threshold=1e-20)      # round 3's cut: 9.6 sigma
+            assert eng.get_option("lsf_fits") == 0
         eng.set_taps(fsf, lsf)
+        assert eng.get_option("lsf_fits") == (0 if lsf_kind == "gauss" else 1)
         eng.set_data(data, var, mask=mask)
         eng.set_params(truth)
         sim = eng.forward()

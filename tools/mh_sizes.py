@@ -28,6 +28,9 @@ for spec in shapes:
         acc = eng.mh_sweeps(n, 3)
         ms = eng.timer_stop()
         ws = 16.0 * D * H * W / 1e6
-        print("zigzag=%s %dx%dx%d (residual + 1/variance %.0f MB): %.3f ms per sweep, %.2f us per launch, "
-              "%.2f M updates/s, accepted %d" % (os.environ.get("D3D_MH_ZIGZAG", "1"), D, H, W, ws, ms / n,
-                                                 ms * 1e3 / n / 121, H * W * n / ms / 1e3, acc), flush=True)
+        frac = 24.0 * D * B.window_voxels(H, W, 11, 11) / 121 / (ms * 1e-3 / n / 121) / 8e12
+        print("zigzag=%s %dx%dx%d (residual + 1/variance %.0f MB; beyond-cache policy %s): %.3f ms per sweep, "
+              "%.2f us per launch, %.2f M updates/s, %.3f of the HBM peak, accepted %d"
+              % (os.environ.get("D3D_MH_ZIGZAG", "1"), D, H, W, ws,
+                 "on" if eng.get_option("mh_nt_ivar_on") else "off", ms / n,
+                 ms * 1e3 / n / 121, H * W * n / ms / 1e3, frac, acc), flush=True)
