@@ -513,6 +513,9 @@ def main():
     ap.add_argument("--no-tiled-leg", action="store_true",
                     help="N > 1, ensemble mode: skip the config-4 leg (one chain tiled over the "
                          "same GPUs, reported as `config4_tiled` beside the ensemble `value`)")
+    ap.add_argument("--only-conv-beyond-mall", action="store_true",
+                    help="run only the 600x600x128 convolution leg and print its record "
+                         "(tools/profile_round.sh: its counters are taken in a run of their own)")
     ap.add_argument("--wait-stdin", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -586,6 +589,9 @@ def main():
     from deconv3d_amd import _lib
 
     D, H, W, fs = WORKLOADS[args.workload]
+    if args.only_conv_beyond_mall:
+        print(json.dumps({"roofline_conv_beyond_mall": conv_beyond_mall_leg(args, local_rank, fs)}))
+        return
     fsf, lsf = build_taps(D, fs)
     eng = _lib.Engine((D, H, W), fsf.shape, device=local_rank)
     eng.set_taps(fsf, lsf)
@@ -712,8 +718,13 @@ def main():
                         "bound": "hbm", "achieved": round(fwd_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(fwd_gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes": fwd_bytes,
                         "ms_per_forward": round(fwd_ms, 4),
-                        "ms_line_build": round(fwd_ms - slots_ms, 4),
-                        "traffic": measured_traffic("k_lines<256>", args.workload)}
+                        "ms_line_build": round(fwd_ms - slots_ms, 4)}
+    # (both launches' counter bytes: the 92 MB line cube is written by one and read by the other)
+    t_lines = measured_traffic("k_lines<256>", args.workload)
+    t_conv = measured_traffic("k_conv_rows<11, 15, true, true, false, 1,", args.workload)
+    roofline_forward["traffic"] = (t_lines + t_conv) if isinstance(t_lines, int) and isinstance(t_conv, int) \
+        else ("stale" if "stale" in (t_lines, t_conv) else None)
+    traffic_rates(roofline_forward, fwd_ms * 1e3)
     eng.chi2_map(fetch=False)
     eng.sync()
     eng.timer_start()

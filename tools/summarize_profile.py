@@ -5,7 +5,12 @@ import json
 import os
 import sys
 
+# usage: summarize_profile.py <dir of rocprofv3 CSVs> <tag> [workload key [file suffix [command]]]
 src, tag = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "c3_300x300x128"
+suffix = sys.argv[4] if len(sys.argv) > 4 else ""
+command = sys.argv[5] if len(sys.argv) > 5 else ("python bench.py --steps 5 --warmup 1 --no-cpu --conv-iters 10 "
+                                                 "--no-conv-beyond-mall")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -79,13 +84,12 @@ for fam, members in families.items():
         agg["l2_hit"] = sum(m["l2_hit"] * m["calls"] for m in members) / calls
     rows.insert(rows.index(members[0]), agg)
 
-with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as fh:
+with open(os.path.join(dst, "%s_kernel_stats%s.csv" % (tag, suffix)), "w") as fh:
     fh.write(open(os.path.join(src, "trace_kernel_stats.csv")).read())
-with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
-    fh.write("# rocprofv3 summary %s\n\n" % tag)
-    fh.write("command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 "
-             "--no-cpu --conv-iters 10 --no-conv-beyond-mall` (+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
-             "`--pmc TCC_HIT_sum TCC_MISS_sum` passes)\n\n")
+with open(os.path.join(dst, "%s_summary%s.md" % (tag, suffix)), "w") as fh:
+    fh.write("# rocprofv3 summary %s%s\n\n" % (tag, suffix))
+    fh.write("command: `rocprofv3 --kernel-trace --stats -- %s` (+ separate `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, "
+             "`--pmc TCC_HIT_sum TCC_MISS_sum` passes)\n\n" % command)
     fh.write("HBM bytes per launch = 2 x FETCH_SIZE KiB (gfx950 correction) + WRITE_SIZE KiB.  "
              "`k_mh_ws<..., *>` rows: launch-weighted mean over the kernel's pending-layer variants "
              "(sixth template argument; the seventh: 1/variance loads with the non-temporal hint), the figure bench.py's `avg_launch_us` compares with.\n\n")
@@ -104,8 +108,8 @@ with open(os.path.join(dst, "%s_summary.md" % tag), "w") as fh:
             fh.write("\n`%s`:\n\n```\n%s```\n" % (name, open(p).read()))
 sys.path.insert(0, root)
 from deconv3d_amd import _lib  # noqa: E402  (the library these counters were taken on)
-json.dump({"tag": tag, "workload": "c3_300x300x128", "source_hash": _lib.source_hash(),
+json.dump({"tag": tag, "workload": workload, "source_hash": _lib.source_hash(),
            "hbm_bytes_per_launch": traffic,
            "hbm_bytes_per_launch_variants": variants},
-          open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
-print(open(os.path.join(dst, "%s_summary.md" % tag)).read()[:3000])
+          open(os.path.join(dst, "%s_traffic%s.json" % (tag, suffix)), "w"), indent=1)
+print(open(os.path.join(dst, "%s_summary%s.md" % (tag, suffix))).read()[:3000])
