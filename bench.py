@@ -351,10 +351,17 @@ def fp64_rates(entry, flops, ms, shape=None, instr_per_pair_step=None, fs=11):
 
 
 def kept_lsf_taps(lsf, bound=1e-16):
-    """Taps d3d_set_taps keeps (Engine.set_taps' default: the smallest are dropped within an
-    error bound of `bound` * sum|lsf|)."""
+    """Taps d3d_set_taps keeps (Engine.set_taps' default): the smallest are dropped within an error
+    bound of `bound` * sum|lsf|; taps of EQUAL magnitude (a symmetric LSF's pairs) stay or go
+    together, so the cut never makes a symmetric LSF asymmetric."""
     mag = np.sort(np.abs(np.asarray(lsf, dtype=np.float64)))
-    return int(mag.size - np.searchsorted(np.cumsum(mag), bound * mag.sum(), side="right"))
+    limit = bound * mag.sum()
+    k = int(np.searchsorted(np.cumsum(mag), limit, side="right"))      # the k smallest fit
+    cut = mag[k - 1] if k > 0 else 0.0
+    while cut > 0.0 and mag[mag <= cut].sum() > limit:
+        below = mag[mag < cut]
+        cut = below.max() if below.size else 0.0
+    return int(np.count_nonzero(mag > cut))
 
 
 def traffic_rates(entry, us):

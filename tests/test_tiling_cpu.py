@@ -213,3 +213,37 @@ def test_bench_starts_its_own_ranks_dry_run():
     assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 3
     assert out["ranks"] == [0, 1] and out["seeds"] == [12345, 12346]
     assert out["config"]["parallelism"] == "ensemble of 2 chains"
+
+
+def test_rank_classes_and_the_critical_path_of_a_tiled_sweep():
+    """a tiled sweep's compute time is the sum over the PHASES of the slowest rank in
+    each (a rank without a part in a phase waits) -- not one rank's total.  rank_classes groups
+    the ranks that run the same launches; critical_path adds up per-phase maxima."""
+    lay = tiling.TileLayout(300, 300, 11, 11, 2, 4)
+    classes = tiling.rank_classes(lay)
+    assert sorted(sum(classes.values(), [])) == list(range(8))
+    # ranks 0-2 own all four parts (FF, FN, NF, NN); rank 7 (last row, last column) only FF
+    by_rank = {r: key for key, ranks in classes.items() for r in ranks}
+    assert [ph for ph, _, _ in by_rank[0]] == [0, 1, 2, 3] and by_rank[0] == by_rank[1] == by_rank[2]
+    assert [ph for ph, _, _ in by_rank[7]] == [0] and [ph for ph, _, _ in by_rank[3]] == [0, 2]
+    strips = tiling.rank_classes(tiling.TileLayout(300, 300, 11, 11, 8, 1))
+    assert all([ph for ph, _, _ in key] in ([0, 2], [0]) for key in strips)
+    # a 2 x 2 grid: rank 0 is the busiest, but the FF phase is set by the rank with the largest FF part
+    times = {0: {0: 2.0, 1: 1.3, 2: 1.3, 3: 1.1}, 1: {0: 2.05, 2: 1.32}, 2: {0: 2.03, 1: 1.31}, 3: {0: 2.1}}
+    total, per_phase, busiest = tiling.critical_path(times)
+    assert abs(total - (2.1 + 1.31 + 1.32 + 1.1)) < 1e-12
+    assert per_phase[0] == (3, 2.1) and per_phase[1] == (2, 1.31) and per_phase[3] == (0, 1.1)
+    assert busiest == 0 and total > sum(times[0].values())
+
+
+def test_bench_counts_the_lsf_taps_the_library_keeps():
+    """bench.kept_lsf_taps mirrors d3d_set_taps' default cut (an error bound of 1e-16 of the sum):
+    the MUSE-like stand-in keeps 17 taps, a Gaussian of sigma 1.0 px fits +-8 channels, one of
+    sigma 1.1 px does not -- and round 3's 1e-20 of the largest tap kept 19 of the sigma-1.0 LSF."""
+    import bench
+    from deconv3d_amd.spread_functions import gaussian_lsf_vector_px, muse_like_lsf_vector
+    assert bench.kept_lsf_taps(muse_like_lsf_vector(128, sigma_px=0.9, box_px=1.0)) == 17
+    g10 = gaussian_lsf_vector_px(128, 1.0)
+    assert bench.kept_lsf_taps(g10) == 17
+    assert int(np.count_nonzero(g10 > 1e-20 * g10.max())) == 19
+    assert bench.kept_lsf_taps(gaussian_lsf_vector_px(128, 1.1)) > 17
