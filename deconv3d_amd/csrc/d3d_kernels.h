@@ -1568,6 +1568,9 @@ struct MHChainArgs {  // one chain of a batch: see MHArgs::batch
     double min_b[3], max_b[3], amp[3];
     double ra;
     uint64_t seed;
+    // (k_mh_small: the chain's tables of the sweep)
+    const MHProposal *props;
+    const double *ltab;
 };
 struct MHArgs {
     int D, Dp, HL, H, W, fh, fw, N, ntaps, npos;

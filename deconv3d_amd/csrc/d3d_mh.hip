@@ -546,6 +546,15 @@ template <bool UV>
 int launch_mh_batch_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
     constexpr int NS = 256;
     const bool few = grid < (unsigned)c->flow_grid / 2;
+    if (P.ltab && layers == 1) {  // the joint launch does not fill the chip either: k_mh_small
+        const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos) * sizeof(double);
+        auto go_small = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(NS), lds, c->stream, P, sweep); };
+        if (c->Dp <= 64) go_small(d3d::k_mh_small<NS, UV, 8, 1, true>);
+        else if (c->Dp <= 128) go_small(d3d::k_mh_small<NS, UV, 8, 2, true>);
+        else go_small(d3d::k_mh_small<NS, UV, 8, 4, true>);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     auto go = [&](auto kern, int M) {
         const size_t lds = d3d::mh_ws_lds_doubles(NS, c->HL, c->Dp, c->N, P.npos, M) * sizeof(double);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(NS + 64), lds, c->stream, P, sweep);
@@ -579,6 +588,9 @@ int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t 
     // two pending layers where the launch of all chains together fills the chip
     const int layers = (L->Dp <= 160 && (long)most * R >= L->flow_grid / 2) ? 2 : 1;
     const bool uv = L->ivar_is_uniform && L->uniform_fast_path;
+    // a joint launch that still does not fill the chip: k_mh_small with the chains' sweep tables
+    bool small = layers == 1;
+    for (int r = 0; r < R; ++r) small = small && mh_small_usable(cs[r]);
     // every chain on the leader's stream for the duration of the call
     std::vector<hipStream_t> own(R);
     for (int r = 0; r < R; ++r) {
@@ -616,12 +628,32 @@ int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t 
             B.ra = c->ra;
             B.seed = c->seed;
             c->props_sweep = -1;
+            B.props = nullptr;
+            B.ltab = nullptr;
+            if (small) {
+                if (!c->props && hipMalloc(&c->props, (size_t)c->HW * sizeof(d3d::MHProposal)) != hipSuccess) rc = fail(D3D_ERR_HIP, "hipMalloc");
+                if (!rc && !c->ltab && hipMalloc(&c->ltab, (size_t)c->HW * 2 * c->Dp * sizeof(double)) != hipSuccess) rc = fail(D3D_ERR_HIP, "hipMalloc");
+                B.props = c->props;
+                B.ltab = c->ltab;
+            }
         }
+        if (rc) break;
+        if (small) rc = ensure_ptab(L);
         if (rc) break;
         if (hipMalloc(&dev, R * sizeof(d3d::MHChainArgs)) != hipSuccess) { rc = fail(D3D_ERR_HIP, "hipMalloc"); break; }
         if (hipMemcpy(dev, host.data(), R * sizeof(d3d::MHChainArgs), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(D3D_ERR_HIP, "hipMemcpy"); break; }
         for (int s = first_sweep; s < first_sweep + n_sweeps && !rc; ++s) {
             const uint32_t rs = (uint32_t)s + L->sweep_origin;
+            if (small) {  // every chain's proposals and lines of this sweep, one launch
+                d3d::MHArgs T;
+                fill_mh_args(L, T);
+                const int n = (L->oy1 - L->oy0) * (L->ox1 - L->ox0);
+                const size_t lds = (size_t)4 * 2 * L->N * sizeof(double);
+                hipLaunchKernelGGL(d3d::k_mh_line_table, dim3((unsigned)(((long)n * R + 3) / 4)), dim3(256), lds,
+                                   L->stream, T, rs, L->oy0, L->oy1, L->ox0, L->ox1, L->props, L->ltab,
+                                   (const d3d::MHChainArgs *)dev, R);
+                if (hipGetLastError() != hipSuccess) { rc = fail(D3D_ERR_HIP, "k_mh_line_table"); break; }
+            }
             int ord = 0;
             for (int col = 0; col < ncol && !rc; ++col) {
                 if (pt.real[col] <= 0) continue;
@@ -629,6 +661,13 @@ int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t 
                 L->pend_part = 0;
                 d3d::MHArgs P;
                 fill_mh_args(L, P);
+                if (small) {
+                    P.props = L->props;   // (replaced per chain in the kernel)
+                    P.ltab = L->ltab;
+                    P.ptab = L->ptab;
+                    P.ptab_row = mh_ptab_row(L, ((col / L->fw - L->gy0) % L->fh + L->fh) % L->fh,
+                                             ((col % L->fw - L->gx0) % L->fw + L->fw) % L->fw);
+                }
                 P.spx = L->spx + pt.off[col];
                 P.rev = (L->mh_zigzag && (ka & 1)) ? 1 : 0;
                 const int n_all = pt.off[col + 1] - pt.off[col];
@@ -705,7 +744,8 @@ int ensure_proposals(d3d_ctx *c, uint32_t sweep) {
     if (n > 0 && lines) {
         const size_t lds = (size_t)4 * 2 * c->N * sizeof(double);
         hipLaunchKernelGGL(d3d::k_mh_line_table, dim3((unsigned)((n + 3) / 4)), dim3(256), lds, c->stream, P,
-                           sweep, c->oy0, c->oy1, c->ox0, c->ox1, c->props, c->ltab);
+                           sweep, c->oy0, c->oy1, c->ox0, c->ox1, c->props, c->ltab,
+                           (const d3d::MHChainArgs *)nullptr, 0);
         HIP_TRY(hipGetLastError());
     } else if (n > 0) {
         hipLaunchKernelGGL(d3d::k_mh_proposals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,

@@ -78,7 +78,11 @@ struct MHRound {
 };
 
 // K: registers per thread that stage the <= 4 pending G rows (4 Dp <= K NS).
-template <int NS, bool UV, int U, int K>
+// BATCH: the launch holds the windows of R independent chains of one geometry, chain-major
+// (d3d_mh_sweeps_batch: Run(..., chains=R) on a cube whose joint launch still does not fill the
+// chip); the chain's cubes, parameters, bounds, random stream and sweep tables replace the
+// arguments' -- work list, taps, position tables and pending-layer geometry are common.
+template <int NS, bool UV, int U, int K, bool BATCH = false>
 __global__ __launch_bounds__(NS) void k_mh_small(MHArgs P, uint32_t sweep) {
     extern __shared__ double smem[];
     const int tid = threadIdx.x;
@@ -115,10 +119,35 @@ __global__ __launch_bounds__(NS) void k_mh_small(MHArgs P, uint32_t sweep) {
     for (int u = 0; u < U; ++u)
         pe0[u] = reinterpret_cast<const double *>(T)[4 * (size_t)min(active ? pos_of(0, u) : npos, npos - 1) + 2];
 
+    int blk = blockIdx.x;
+    if constexpr (BATCH) {
+        const int r = blockIdx.x / P.b_items;
+        blk = blockIdx.x - r * P.b_items;
+        const MHChainArgs &B = P.batch[r];
+        P.err = B.err;
+        P.ivar = B.ivar;
+        P.ivar_uniform = B.ivar_uniform;
+        P.params = B.params;
+        P.prev = B.prev;
+        P.dlog = B.dlog;
+        P.accepted = B.accepted;
+        P.Gcur = B.gbuf[P.b_gcur];
+        P.lay_G[0] = B.gbuf[P.b_lay_g[0]];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            P.min_b[k] = B.min_b[k];
+            P.max_b[k] = B.max_b[k];
+            P.amp[k] = B.amp[k];
+        }
+        P.ra = B.ra;
+        P.seed = B.seed;
+        P.props = B.props;
+        P.ltab = B.ltab;
+    }
     // (measured and dropped: the window centre from the block index -- the grid as the launch's
     // lattice, no work-list entry to wait for: 10.87 against 10.89 us per launch at 64^3, 12.22
     // against 12.27 for an 8x1 strip; the scalar load of the entry hides behind the table loads)
-    const int4 ent = P.spx[blockIdx.x];
+    const int4 ent = P.spx[blk];
     const int y = ent.x, x = ent.y;  // may lie outside the cube when virtual
     const bool real = ent.z != 0;
     const int sp = y * P.W + x;
@@ -303,14 +332,34 @@ __global__ __launch_bounds__(NS) void k_mh_small(MHArgs P, uint32_t sweep) {
 // and the LSF-convolved unit lines of its current and proposed (c, w) -- one wavefront per
 // spaxel running the code of k_mh_ws's prepare wavefront (zero-extended unit lines in a
 // wave-private LDS region, mh_lsf per channel): the same bits.
+// batch != NULL: the tables of R chains in one launch (grid over R x spaxels, chain-major): the
+// chain's parameters, bounds, random stream and table pointers replace the arguments'.
 static __global__ __launch_bounds__(256) void k_mh_line_table(MHArgs P, uint32_t sweep, int y0, int y1,
                                                                int x0, int x1, MHProposal *props,
-                                                               double *ltab) {
+                                                               double *ltab, const MHChainArgs *batch,
+                                                               int n_chains) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
+    int i = blockIdx.x * 4 + wave;
     const int w = x1 - x0;
-    if (i >= (y1 - y0) * w) return;
+    const int n_sp = (y1 - y0) * w;
+    if (batch) {
+        const int r = i / n_sp;
+        if (r >= n_chains) return;
+        i -= r * n_sp;
+        const MHChainArgs &B = batch[r];
+        P.params = B.params;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            P.min_b[k] = B.min_b[k];
+            P.max_b[k] = B.max_b[k];
+            P.amp[k] = B.amp[k];
+        }
+        P.seed = B.seed;
+        props = const_cast<MHProposal *>(B.props);
+        ltab = const_cast<double *>(B.ltab);
+    }
+    if (i >= n_sp) return;
     const int y = y0 + i / w, x = x0 + i % w;
     const long sp = (long)y * P.W + x;
     if (!P.mask[sp]) return;
