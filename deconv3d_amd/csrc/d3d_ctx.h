@@ -23,7 +23,12 @@
 // The WIDE form of a small colour launch at 128 channels: eleven
 // streaming wavefronts per window instead of four -- one per window row of an 11 x 11 FSF
 // -- in workgroups of 768 threads.
-constexpr int MH_WIDE_NS = 704;
+// (round 4, same-box A/B with k_mh_small through tools/build_variant.sh -DD3D_WIDE_NS=512: eight
+// wavefronts, two per SIMD, 11.95 us per launch of an 8x1 strip against 11.79 with eleven)
+#ifndef D3D_WIDE_NS
+#define D3D_WIDE_NS 704
+#endif
+constexpr int MH_WIDE_NS = D3D_WIDE_NS;
 // k_mh_chain: at most this many threads per workgroup (three wavefronts per SIMD: 168
 // registers each, of which a thread's column of an 11-row window takes 88)
 constexpr int MH_CHAIN_NT = 768;

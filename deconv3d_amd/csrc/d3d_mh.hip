@@ -272,7 +272,7 @@ int launch_mh_small(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sw
     // Eight window positions (sixteen loads) in flight per thread, six in the wide form (704
     // threads leave 168 registers; eleven spilled: 15.9 us per launch against 11.9).  Measured
     // beside it at 64^3: four 11.0 us, eight 10.5, sixteen (250 registers) 10.4.
-    if (wide) return launch_mh_small_t<UV, MH_WIDE_NS, 6, 1>(c, P, grid, sweep);
+    if (wide) return launch_mh_small_t<UV, MH_WIDE_NS, (MH_WIDE_NS > 512 ? 6 : 8), 1>(c, P, grid, sweep);
     if (c->Dp <= 64) return launch_mh_small_t<UV, 256, 8, 1>(c, P, grid, sweep);
     if (c->Dp <= 128) return launch_mh_small_t<UV, 256, 8, 2>(c, P, grid, sweep);
     return launch_mh_small_t<UV, 256, 8, 4>(c, P, grid, sweep);

@@ -238,20 +238,38 @@ __global__ __launch_bounds__(NS) void k_mh_small(MHArgs P, uint32_t sweep) {
         for (int u = 0; u < U; ++u) request(bits[u], pos[u], R, u);
     };
     double2 sA = make_double2(0.0, 0.0), sB = sA, sC = sA;
-    auto consume = [&](MHRound<U> &R, int u) {
-        if (!(R.fl[u] & 1u)) return;
-        // (two independent LDS reads: this position's taps, the staged G row)
-        const double2 ff = *reinterpret_cast<const double2 *>(s_tab + 4 * (size_t)(R.fl[u] >> 4));
-        const double2 gz = *reinterpret_cast<const double2 *>(
-            reinterpret_cast<const char *>(s_gp) + ((R.fl[u] >> 2) & 3u) * col_bytes + zoff);
-        double2 e = R.e[u];
-        if (R.fl[u] & 2u) {  // the pending layer: e <- e + f G
-            e.x = fma(ff.y, gz.x, e.x);
-            e.y = fma(ff.y, gz.y, e.y);
-            if (P.write_back)
-                *reinterpret_cast<double2 *>(reinterpret_cast<char *>(P.err) + R.off[u]) = e;
+    // A round's LDS reads -- each position's taps (own, pending) and its staged G row -- are
+    // issued TOGETHER, unconditionally (clamped indices), before the arithmetic: one wait per
+    // batch of UB positions instead of two dependent waits per position, which a workgroup that is
+    // alone on its compute unit (one wavefront per SIMD) cannot hide.
+    constexpr int UB = (NS > 512) ? (U + 1) / 2 : U;  // (the wide form's 168 registers: half rounds)
+    auto consume = [&](MHRound<U> &R) {
+#pragma unroll
+        for (int b = 0; b < U; b += UB) {
+            double2 ff[UB], gz[UB];
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int u = b + k;
+                if (u < U) {
+                    ff[k] = *reinterpret_cast<const double2 *>(s_tab + 4 * (size_t)(R.fl[u] >> 4));
+                    gz[k] = *reinterpret_cast<const double2 *>(
+                        reinterpret_cast<const char *>(s_gp) + ((R.fl[u] >> 2) & 3u) * col_bytes + zoff);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < UB; ++k) {
+                const int u = b + k;
+                if (u >= U || !(R.fl[u] & 1u)) continue;
+                double2 e = R.e[u];
+                if (R.fl[u] & 2u) {  // the pending layer: e <- e + f G
+                    e.x = fma(ff[k].y, gz[k].x, e.x);
+                    e.y = fma(ff[k].y, gz[k].y, e.y);
+                    if (P.write_back)
+                        *reinterpret_cast<double2 *>(reinterpret_cast<char *>(P.err) + R.off[u]) = e;
+                }
+                D3D_ACCUM(e, R.v[u], ff[k].x);
+            }
         }
-        D3D_ACCUM(e, R.v[u], ff.x);
     };
     MHRound<U> A;
     if (active) {  // round 0 flies during the setup (its table entries straight from memory)
@@ -279,8 +297,7 @@ __global__ __launch_bounds__(NS) void k_mh_small(MHArgs P, uint32_t sweep) {
         // sit between two consumes; and two buffers of four positions, 10.4)
         for (int r = 0; r < rounds; ++r) {
             if (r > 0) issue(r, A);
-#pragma unroll
-            for (int u = 0; u < U; ++u) consume(A, u);
+            consume(A);
         }
         if (real) {
             double *rr = s_red + (size_t)g * 3 * Dp + 2 * zl;

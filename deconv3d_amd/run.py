@@ -278,6 +278,10 @@ class Run:
                 self.chains[r][0] = min_boundaries + (max_boundaries - min_boundaries) * draws
 
         # ---- device context ----------------------------------------------
+        if self._host_model and n_chains > 1:
+            raise NotImplementedError("chains= needs a line model evaluated on the device "
+                                      "(SingleGaussianLineModel); %s runs on the host"
+                                      % type(self.model).__name__)
         self.engines = []
         for r in range(n_chains):
             eng = _lib.Engine(cube_shape, self.fsf.shape, device=device)
@@ -286,10 +290,6 @@ class Run:
             eng.set_data(self.cube.data, self.variance_cube, mask=self.mask)
         self.engine = self.engines[0]
         host_chain = None
-        if self._host_model and n_chains > 1:
-            raise NotImplementedError("chains= needs a line model evaluated on the device "
-                                      "(SingleGaussianLineModel); %s runs on the host"
-                                      % type(self.model).__name__)
         if self._host_model:
             from .host_model import HostModelChain
             self.logger.info("Line model %s is evaluated on the host (slower path)."
