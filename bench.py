@@ -651,7 +651,8 @@ def main():
     launches = ncol * args.steps
     avg_launch_us = dev_ms * 1e3 / launches
     achieved = bytes_per_sweep / ncol / (avg_launch_us * 1e-6) / 1e9
-    roofline = {"kernel": "k_mh_ws (one launch per colour class)", "bound": "hbm",
+    small = eng.get_option("small_parts") > 0       # launches that do not fill the chip: k_mh_small
+    roofline = {"kernel": ("k_mh_small" if small else "k_mh_ws") + " (one launch per colour class)", "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": measured_traffic("k_mh_ws<256, false, 2, 2, 2,", args.workload, "false, false, false>"),

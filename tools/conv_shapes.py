@@ -14,8 +14,14 @@ from deconv3d_amd.spread_functions import moffat_image, muse_like_lsf_vector
 
 CASES = [(128, 300, 300, 15), (128, 300, 300, 13), (128, 300, 300, 11), (256, 300, 300, 15),
          (21, 30, 24, 15), (30, 300, 300, 11), (48, 300, 300, 11), (100, 300, 300, 11), (100, 300, 300, 15)]
+from deconv3d_amd.spread_functions import gaussian_image
+CASES.append((128, 300, 300, -11))      # a rotated elliptical Gaussian (pa = 30 deg, ba = 0.7): point symmetry only
 for D, H, W, fs in CASES:
-    fsf = moffat_image((fs, fs), beta=2.5, fwhm_px=3.0 if fs <= 11 else 4.0)
+    if fs < 0:
+        fsf = gaussian_image(4.0, pa=30., ba=0.7)
+        fs = fsf.shape[0]
+    else:
+        fsf = moffat_image((fs, fs), beta=2.5, fwhm_px=3.0 if fs <= 11 else 4.0)
     lsf = muse_like_lsf_vector(D, sigma_px=0.9, box_px=1.0)
     for opts in ({}, {"conv_zb": 0} if D != 128 else {"conv_rows": 0}):
         with _lib.Engine((D, H, W), fsf.shape, options=opts) as eng:
