@@ -245,8 +245,7 @@ int build_colour_lists(d3d_ctx *c) {
         const bool partitioned = c->tiled || !c->part_rects.empty();
         pt.wide = pt.layers == 1 && c->mh_wide && partitioned && c->Dp == 128 && most > 0 &&
                   most <= c->flow_grid / 4 && c->mh_defer == 1;
-        // (option mh_small = 2, measurements only: every one-layer part, chip-filling or not)
-        pt.small = pt.layers == 1 && (most_wgs < c->flow_grid / 2 || c->mh_small == 2);
+        pt.small = pt.layers == 1 && most_wgs < c->flow_grid / 2;
         // k_mh_chain: whole sweeps of the part in one launch of persistent workgroups, one per
         // lattice slot -- where every slot is resident at once (one workgroup per CU) and a
         // thread can hold its share of the window in registers
@@ -734,7 +733,7 @@ int d3d_ctx_get_option(d3d_ctx *c, const char *key, long *value) {
     }
     if (!strcmp(key, "small_parts")) {    // parts whose colour launches run k_mh_small
         long n = 0;
-        for (const d3d_ctx::Part &pt : c->parts) n += (pt.small && d3dh::mh_small_usable(c)) ? 1 : 0;
+        for (const d3d_ctx::Part &pt : c->parts) n += d3dh::mh_part_uses_tables(c, pt) ? 1 : 0;
         *value = c->have_data ? n : 0;
         return D3D_OK;
     }
@@ -1357,9 +1356,11 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         (void)pairs;
 #endif
         // small colour launches: the sweep's proposals come from one launch before them
-        // (and the z-blocked kernels: every block's prepare wavefront and k_mh_zdecide need it)
+        // (and the z-blocked kernels: every block's prepare wavefront and k_mh_zdecide need it;
+        // and every part that runs k_mh_small)
+        const bool tables = deferred && c->mh_defer == 1 && !c->mh_zb && d3dh::mh_part_uses_tables(c, pt);
         const bool use_props =
-            c->mh_props && deferred && (c->mh_zb || (pt.layers == 1 && !c->deep));
+            c->mh_props && deferred && (c->mh_zb || (pt.layers == 1 && !c->deep) || tables);
         if (use_props)
             if (int rc = ensure_proposals(c, sweep)) return rc;
         d3d::MHArgs P;
@@ -1368,11 +1369,12 @@ int run_part(d3d_ctx *c, int pi, uint32_t sweep) {
         P.rev = (c->mh_zigzag && (ka & 1)) ? 1 : 0;
         if (use_props) P.props = c->props;
         // (k_mh_small reads the sweep's line table, built with the proposals)
-        if (use_props && pt.small && d3dh::mh_small_usable(c)) {
+        if (use_props && tables) {
             P.ltab = c->ltab;
             P.ptab = c->ptab;
-            P.ptab_row = d3dh::mh_ptab_row(c, ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh,
-                                           ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw);
+            const int ly = ((col / c->fw - c->gy0) % c->fh + c->fh) % c->fh;
+            const int lx = ((col % c->fw - c->gx0) % c->fw + c->fw) % c->fw;
+            for (int j = 0; j < 2; ++j) P.ptab_row[j] = d3dh::mh_ptab_row(c, ly, lx, j);
         }
         if (deferred) {
             // real + virtual positions: the windows of this launch tile the domain

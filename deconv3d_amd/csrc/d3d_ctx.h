@@ -294,7 +294,9 @@ int ensure_proposals(d3d_ctx *c, uint32_t sweep);
 // k_mh_small can take this context's small parts (depth, tap count, options)
 bool mh_small_usable(const d3d_ctx *c);
 // row of the position tables for a launch of local colour residues (ly, lx) over the pending layer
-int mh_ptab_row(const d3d_ctx *c, int ly, int lx);
+int mh_ptab_row(const d3d_ctx *c, int ly, int lx, int layer = 0);
+// the part's colour launches run k_mh_small (its small form, or -- option mh_small = 2 -- the chip-filling one)
+bool mh_part_uses_tables(const d3d_ctx *c, const d3d_ctx::Part &pt);
 // n_sweeps whole sweeps (Philox numbers sweep0 ..) of part pi in one launch (Part::chain)
 #ifdef D3D_EXPERIMENTS
 int launch_mh_chain(d3d_ctx *c, int pi, uint32_t sweep0, int n_sweeps);

@@ -1669,7 +1669,7 @@ struct MHArgs {
     // ... and the relative position tables of the context (d3d_mh_small.h: MHPos), with the
     // row of this launch's pair of colour classes
     const double *ptab;
-    int ptab_row;
+    int ptab_row[2];  // (one per pending layer the kernel can apply)
 #ifdef D3D_EXPERIMENTS
     // k_mh_ws phase stamps (100 MHz wall clock), 8 slots per workgroup: 0 entry,
     // 1 setup done, 2 window streamed, 3 prepare wavefront done, 4 update written

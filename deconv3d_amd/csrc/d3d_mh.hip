@@ -56,7 +56,7 @@ void fill_mh_args(d3d_ctx *c, d3d::MHArgs &P) {
     P.ltab = nullptr;   // (and the line table for those that run k_mh_small)
     P.fw_inv = (65536 + c->fw - 1) / c->fw;
     P.ptab = nullptr;
-    P.ptab_row = c->fh * c->fw;
+    P.ptab_row[0] = P.ptab_row[1] = c->fh * c->fw;
     P.batch = nullptr;  // (mh_sweeps_batch)
     P.b_items = 0;
     P.b_gcur = 0;
@@ -211,14 +211,29 @@ bool mh_small_usable(const d3d_ctx *c) {
            c->fh <= 31 && c->fw <= 31 && (double)c->cube_elems * 8.0 < 4294967296.0;
 }
 
-int mh_ptab_row(const d3d_ctx *c, int ly, int lx) {
-    if (c->lay_n < 1) return c->fh * c->fw;  // nothing pending
+int mh_ptab_row(const d3d_ctx *c, int ly, int lx, int layer) {
+    if (layer >= c->lay_n) return c->fh * c->fw;  // nothing pending there
     const int fhh = (c->fh - 1) / 2, fhw = (c->fw - 1) / 2;
     // any window of the class: the offset of the covering pending spaxel is the same for all
     const int y = ly + 4 * c->fh, x = lx + 4 * c->fw;
-    const int oy = d3d::mh_raw_cover(y - fhh, c->lay_cy[c->lay_n - 1], c->fh, fhh) - (y - fhh);
-    const int ox = d3d::mh_raw_cover(x - fhw, c->lay_cx[c->lay_n - 1], c->fw, fhw) - (x - fhw);
+    const int oy = d3d::mh_raw_cover(y - fhh, c->lay_cy[layer], c->fh, fhh) - (y - fhh);
+    const int ox = d3d::mh_raw_cover(x - fhw, c->lay_cx[layer], c->fw, fhw) - (x - fhw);
     return (oy + fhh) * c->fw + (ox + fhw);
+}
+
+bool mh_part_uses_tables(const d3d_ctx *c, const d3d_ctx::Part &pt) {
+    if (!mh_small_usable(c)) return false;
+    if (pt.small) return true;
+#ifdef D3D_EXPERIMENTS
+    // the chip-filling form (option mh_small = 2): one or two pending layers, 256 streaming
+    // threads.  Bit-identical to k_mh_ws and measured SLOWER than it -- 43.7 against 40.6 us per
+    // launch at 300x300x128, 79.6 against 76.8 at 256 channels, 27.7 against 26.5 at 64
+    // (profiles/r04_table_kernel_full.txt): a launch that fills the chip is bound by HBM, not by
+    // the instruction issue the tables save, and the tables themselves are 3 % more traffic.
+    return c->mh_small == 2 && pt.layers <= 2 && !pt.wide;
+#else
+    return false;
+#endif
 }
 
 // The relative position tables of k_mh_small (d3d_mh_small.h: MHPos), once per set of taps.
@@ -257,18 +272,45 @@ static int ensure_ptab(d3d_ctx *c) {
     return 0;
 }
 
-template <bool UV, int NS, int U, int K>
+template <bool UV, int NS, int U, int K, int M = 1, bool FULL = false, bool NTV = false>
 int launch_mh_small_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep) {
-    const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos) * sizeof(double);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_small<NS, UV, U, K>), dim3(grid), dim3(NS), lds, c->stream,
-                       P, sweep);
+    const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos, M) * sizeof(double);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_mh_small<NS, UV, U, K, false, M, FULL, NTV>), dim3(grid), dim3(NS),
+                       lds, c->stream, P, sweep);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
+#ifdef D3D_EXPERIMENTS
+// The chip-filling form (EXPERIMENTS builds, option mh_small = 2): one or two pending layers, two
+// positions in flight per thread, ONE deciding wavefront; beyond the Infinity Cache the
+// non-temporal / write-through policy.
+template <bool UV, int K>
+int launch_mh_small_full(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, int layers) {
+    bool ntv = false;
+    if constexpr (!UV) ntv = c->mh_nt_ivar;
+    if (layers >= 2) {
+        if constexpr (!UV)
+            if (ntv) return launch_mh_small_t<UV, 256, 2, K, 2, true, true>(c, P, grid, sweep);
+        return launch_mh_small_t<UV, 256, 2, K, 2, true, false>(c, P, grid, sweep);
+    }
+    if constexpr (!UV)
+        if (ntv) return launch_mh_small_t<UV, 256, 2, K, 1, true, true>(c, P, grid, sweep);
+    return launch_mh_small_t<UV, 256, 2, K, 1, true, false>(c, P, grid, sweep);
+}
+#endif
+
 template <bool UV>
-int launch_mh_small(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, bool wide) {
-    NEED(P.n_lay <= 1 && P.ltab && P.props, D3D_ERR_STATE, "internal: k_mh_small with %d pending layers", P.n_lay);
+int launch_mh_small(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep, bool wide, int layers,
+                    bool full) {
+    NEED(P.n_lay <= layers && layers <= 2 && P.ltab && P.props, D3D_ERR_STATE,
+         "internal: k_mh_small with %d pending layers of %d", P.n_lay, layers);
+#ifdef D3D_EXPERIMENTS
+    if (full) return launch_mh_small_full<UV, 4>(c, P, grid, sweep, layers);
+#else
+    (void)full;
+#endif
+    NEED(layers == 1, D3D_ERR_STATE, "internal: the small form keeps one pending layer");
     // Eight window positions (sixteen loads) in flight per thread, six in the wide form (704
     // threads leave 168 registers; eleven spilled: 15.9 us per launch against 11.9).  Measured
     // beside it at 64^3: four 11.0 us, eight 10.5, sixteen (250 registers) 10.4.
@@ -293,7 +335,8 @@ int launch_mh_ws(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t sweep
     // 35.2 -> 33.3 us per colour; the general one loses, 43.5 -> 49.7)
     const bool small = UV || grid < (unsigned)c->flow_grid / 2;
     // (round 4: the parts whose launches do not fill the chip -- run_part hands them the line table)
-    if (P.ltab && layers == 1) return launch_mh_small<UV>(c, P, grid, sweep, wide);
+    if (P.ltab && layers <= 2)
+        return launch_mh_small<UV>(c, P, grid, sweep, wide, layers, !(grid < (unsigned)c->flow_grid / 2));
     // 257 .. 512 channels (round 3): the same kernel with 512 streaming threads (thread <->
     // channel in the tail; the staged G rows, 4 Dp <= 4 x 576, in four registers); the position
     // groups (512 / HL) are those of k_mh_defer<512>, so the chain stays bit-identical to it
@@ -547,7 +590,7 @@ int launch_mh_batch_t(d3d_ctx *c, const d3d::MHArgs &P, unsigned grid, uint32_t 
     constexpr int NS = 256;
     const bool few = grid < (unsigned)c->flow_grid / 2;
     if (P.ltab && layers == 1) {  // the joint launch does not fill the chip either: k_mh_small
-        const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos) * sizeof(double);
+        const size_t lds = d3d::mh_small_lds_doubles(NS, c->HL, c->Dp, P.npos, 1) * sizeof(double);
         auto go_small = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid), dim3(NS), lds, c->stream, P, sweep); };
         if (c->Dp <= 64) go_small(d3d::k_mh_small<NS, UV, 8, 1, true>);
         else if (c->Dp <= 128) go_small(d3d::k_mh_small<NS, UV, 8, 2, true>);
@@ -665,8 +708,8 @@ int mh_sweeps_batch(d3d_ctx **cs, int R, int n_sweeps, int first_sweep, int64_t 
                     P.props = L->props;   // (replaced per chain in the kernel)
                     P.ltab = L->ltab;
                     P.ptab = L->ptab;
-                    P.ptab_row = mh_ptab_row(L, ((col / L->fw - L->gy0) % L->fh + L->fh) % L->fh,
-                                             ((col % L->fw - L->gx0) % L->fw + L->fw) % L->fw);
+                    P.ptab_row[0] = mh_ptab_row(L, ((col / L->fw - L->gy0) % L->fh + L->fh) % L->fh,
+                                                ((col % L->fw - L->gx0) % L->fw + L->fw) % L->fw);
                 }
                 P.spx = L->spx + pt.off[col];
                 P.rev = (L->mh_zigzag && (ka & 1)) ? 1 : 0;
@@ -736,8 +779,7 @@ int ensure_proposals(d3d_ctx *c, uint32_t sweep) {
     const int n = (c->oy1 - c->oy0) * (c->ox1 - c->ox0);
     // with the lines of every update where a part runs k_mh_small (one wavefront per spaxel)
     bool lines = false;
-    if (mh_small_usable(c))
-        for (const d3d_ctx::Part &pt : c->parts) lines = lines || pt.small;
+    for (const d3d_ctx::Part &pt : c->parts) lines = lines || mh_part_uses_tables(c, pt);
     if (lines && !c->ltab) HIP_TRY(hipMalloc(&c->ltab, (size_t)c->HW * 2 * c->Dp * sizeof(double)));
     if (lines)
         if (int rc = ensure_ptab(c)) return rc;

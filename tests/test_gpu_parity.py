@@ -388,6 +388,60 @@ def test_small_launch_kernel_wide_form_is_bit_identical_to_round3s():
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("kind", ["two layers", "one layer", "uniform variance", "beyond-cache policy",
+                                  "two layers, 64 channels", "masked, odd depth"])
+def test_table_kernel_chip_filling_form_is_bit_identical_to_k_mh_ws(kind):
+    """k_mh_small's chip-filling form (option mh_small = 2: relative position tables, the sweep's
+    line table, one or two pending layers, ONE deciding wavefront, optionally the non-temporal /
+    write-through policy) against k_mh_ws on launches that fill the chip (>= 512 windows per
+    colour class): the same chain bit for bit -- parameters, carried residual, log-ratio map,
+    accepted count -- over three sweeps and a from-scratch residual.  (An EXPERIMENTS-build
+    kernel: correct, and measured slower than k_mh_ws -- a launch that fills the chip is bound by
+    HBM, not by instruction issue)"""
+    from deconv3d_amd import _lib
+    if not _lib.has_experiments():
+        pytest.skip("the chip-filling form of k_mh_small is compiled with make EXPERIMENTS=1 only")
+    rng = np.random.default_rng(31)
+    D = {"two layers, 64 channels": 64, "masked, odd depth": 21}.get(kind, 16)
+    H, W = 256, 254                                # 25 x 25 = 625 windows per colour class
+    fsf = O.moffat_cropped(11, 3.0, 2.5)
+    lsf = O.gaussian_lsf_vector(D, 0.9088)
+    y, x = np.indices((H, W))
+    truth = np.dstack((1.0 + 9.0 * np.exp(-((y - H / 2.) ** 2 + (x - W / 2.) ** 2) / (2. * 60. ** 2)),
+                       D * (0.3 + 0.4 * rng.random((H, W))), 0.8 + 1.5 * rng.random((H, W))))
+    mask = np.ones((H, W))
+    if kind == "masked, odd depth":
+        mask[rng.integers(0, H, 200), rng.integers(0, W, 200)] = 0
+    opts = {"mh_layers": 1} if kind == "one layer" else {}
+    if kind == "beyond-cache policy":
+        opts["mh_nt_ivar"] = 1
+    outs = []
+    for small in (2, 1):
+        with _lib.Engine((D, H, W), fsf.shape, options=dict(opts, mh_small=small)) as eng:
+            eng.set_taps(fsf, lsf)
+            eng.set_params(truth)
+            clean = eng.forward()
+            sigma = 0.05 * clean.max()
+            data = clean + np.random.default_rng(5).normal(0., sigma, clean.shape)
+            var = (sigma * (0.5 + np.random.default_rng(6).random(clean.shape))) ** 2
+            if kind == "uniform variance":
+                eng.set_data(data, None, var_scalar=sigma ** 2, mask=mask)
+                assert eng.variance_is_uniform()
+            else:
+                eng.set_data(data, var, mask=mask)
+            assert eng.mh_layers() == (1 if kind == "one layer" else 2)
+            assert eng.get_option("small_parts") == (1 if small == 2 else 0)
+            max_b = np.array([data.max() / fsf.max(), D - 1., float(D)])
+            init = max_b * np.random.default_rng(7).random((H, W, 3))
+            init[..., 2] = np.maximum(init[..., 2], 0.3)
+            eng.set_params(init)
+            eng.mh_config(np.zeros(3), max_b, 0.1, float(max_b[0] ** 2), seed=11, refresh_every=2)
+            acc = eng.mh_sweeps(3, 1)
+            outs.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), np.array([acc])))
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_options_belong_to_a_context_not_to_the_process(monkeypatch):
     """VERDICT r2 item 8 on the default build: three contexts of one process with different
     kernel families, alive together and stepped in turn, each keep their own setting and
