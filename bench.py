@@ -312,7 +312,7 @@ def measured_traffic(kernel_prefix, workload, kernel_suffix=""):
     if not os.path.isdir(pdir):
         return None
     for name in sorted(os.listdir(pdir)):
-        if not name.endswith("_traffic.json"):
+        if "_traffic" not in name or not name.endswith(".json"):     # r04_traffic.json, r04_traffic_conv600.json
             continue
         try:
             rec = json.load(open(os.path.join(pdir, name)))
