@@ -77,7 +77,9 @@ class Run:
     ``Run(..., seed=seed + r)``), ``extract_parameters`` pools the chains, ``run.rhat`` is the
     per-parameter Gelman-Rubin map, ``run.acceptance_rates`` the per-chain rates; the stopping
     rule looks at the pooled acceptance rate.  ``initial_parameters`` may be 4-D, one map per
-    chain.  Checkpoints and custom (host-evaluated) line models take one chain.
+    chain; a checkpoint holds all R chains (``<prefix>_parameters.npy`` is that 4-D array, chain
+    r > 0's slots are ``<prefix>_c<r>_chain.npy``) and resumes R chains.  Custom (host-evaluated)
+    line models take one chain.
     """
 
     def __init__(
@@ -113,8 +115,6 @@ class Run:
         self.write_every = int(write_every)
         n_chains = int(chains)
         assert n_chains >= 1, "chains= MUST be a positive integer"
-        if n_chains > 1 and (checkpoint is not None or resume_state is not None):
-            raise NotImplementedError("checkpoint= / resume_state= take one chain (chains=1)")
         self.n_chains = n_chains
 
         # ---- input cube (lib/run.py:119-143) --------------------------------
@@ -277,6 +277,29 @@ class Run:
                     (cube_height, cube_width, parameters_count))
                 self.chains[r][0] = min_boundaries + (max_boundaries - min_boundaries) * draws
 
+        # a resumed run continues the checkpointed run's sweep numbering: sweep s of
+        # this segment draws the random numbers of sweep s + origin
+        self.sweep_origin = 0
+        resumed_accepted = None
+        resumed_per_chain = None
+        if resume_state is not None:
+            state = np.load(resume_state) if isinstance(resume_state, str) else resume_state
+            files = getattr(state, "files", state)
+            saved_chains = int(state["n_chains"]) if "n_chains" in files else 1
+            if saved_chains != n_chains:
+                raise ValueError("resume_state holds %d chain(s), this run has chains=%d"
+                                 % (saved_chains, n_chains))
+            if int(state["seed"]) != self.seed:
+                self.logger.warning("resume_state was written with seed %d, this run uses %d"
+                                    % (int(state["seed"]), self.seed))
+            self.sweep_origin = int(state["sweep_origin"]) + int(state["iteration"]) - 1
+            # totals over every earlier segment (older checkpoints hold one segment's)
+            resumed_accepted = (
+                int(state["total_accepted"] if "total_accepted" in files else state["accepted_count"]),
+                int(state["total_iterations"] if "total_iterations" in files else state["iteration"]))
+            if n_chains > 1 and "per_chain_accepted" in files:
+                resumed_per_chain = [int(v) for v in state["per_chain_accepted"]]
+
         # ---- device context ----------------------------------------------
         if self._host_model and n_chains > 1:
             raise NotImplementedError("chains= needs a line model evaluated on the device "
@@ -304,23 +327,10 @@ class Run:
                 eng.mh_config(min_boundaries, max_boundaries, jumping_amplitude,
                               gibbs_apriori_variance, seed=self.seed + r,
                               refresh_every=refresh_every)
-        # a resumed run continues the checkpointed run's sweep numbering: sweep s of
-        # this segment draws the random numbers of sweep s + origin
-        self.sweep_origin = 0
-        resumed_accepted = None
         if resume_state is not None:
-            state = np.load(resume_state) if isinstance(resume_state, str) else resume_state
-            if int(state["seed"]) != self.seed:
-                self.logger.warning("resume_state was written with seed %d, this run uses %d"
-                                    % (int(state["seed"]), self.seed))
-            self.sweep_origin = int(state["sweep_origin"]) + int(state["iteration"]) - 1
-            # totals over every earlier segment (older checkpoints hold one segment's)
-            files = getattr(state, "files", state)
-            resumed_accepted = (
-                int(state["total_accepted"] if "total_accepted" in files else state["accepted_count"]),
-                int(state["total_iterations"] if "total_iterations" in files else state["iteration"]))
             if host_chain is None:
-                self.engine.set_sweep_origin(self.sweep_origin)
+                for eng in self.engines:
+                    eng.set_sweep_origin(self.sweep_origin)
             else:
                 host_chain.set_sweep_origin(self.sweep_origin)
         self.logger.info("Iteration #1")
@@ -339,8 +349,13 @@ class Run:
         self._resumed_from = resumed_accepted
         import time as _time
         self.mh_seconds = 0.0                      # wall time of the device calls of the loop
-        self._acc_base = resumed_accepted[0] - spaxels_count if resumed_accepted else 0
+        self._acc_base = resumed_accepted[0] - spaxels_count * n_chains if resumed_accepted else 0
         self._it_base = resumed_accepted[1] - 1 if resumed_accepted else 0
+        # (per chain: what the checkpoint recorded, else an even share of the total)
+        if resumed_accepted and resumed_per_chain is None:
+            resumed_per_chain = [resumed_accepted[0] // n_chains] * n_chains
+        self._acc_base_chain = [a - spaxels_count for a in resumed_per_chain] if resumed_accepted \
+            else [0] * n_chains
         # the reference re-evaluates the stopping rule (and logs) every sweep
         # (lib/run.py:344-364): one sweep per device call whenever the rule is
         # armed, so that the run stops exactly where the reference would; with
@@ -382,13 +397,13 @@ class Run:
             # reference; here it is the checkpoint cadence when a path is given
             if checkpoint is not None and before // write_every != cur_iteration // write_every:
                 self.iterations_done = cur_iteration
-                self._write_checkpoint(checkpoint, cur_iteration, accepted_count)
+                self._write_checkpoint(checkpoint, cur_iteration, accepted_count, per_chain_accepted)
         self.iterations_done = cur_iteration
         self.acceptance_rate = float(accepted_count + self._acc_base) / \
             float(max(spaxels_count * n_chains * (cur_iteration + self._it_base), 1))
         if n_chains > 1:
-            self.acceptance_rates = [a / float(max(spaxels_count * cur_iteration, 1))
-                                     for a in per_chain_accepted]
+            self.acceptance_rates = [(a + b) / float(max(spaxels_count * (cur_iteration + self._it_base), 1))
+                                     for a, b in zip(per_chain_accepted, self._acc_base_chain)]
         else:
             self.acceptance_rates = [self.acceptance_rate]
         if chain_file is not None:
@@ -461,30 +476,45 @@ class Run:
             between = tail.mean(axis=1).var(axis=0, ddof=1)
             return np.sqrt(((n - 1.) / n * within + between) / within)
 
-    def _write_checkpoint(self, name, iteration, accepted_count):
+    def _write_checkpoint(self, name, iteration, accepted_count, per_chain_accepted=None):
         """`<name>_parameters.npy` (current map, reusable as initial_parameters,
         lib/run.py:790-797), `<name>_chain.npy` (slots written so far) and
         `<name>_state.npz` (iteration, seed, accepted count, `n_valid` = chain slots
         written so far: `resume_state=`).
         A memory-mapped chain (`chain_file=`) is flushed where it lives instead of
         copied: the checkpoint then names its files, and `chain_file == checkpoint`
-        cannot rewrite the file under the open mapping."""
-        np.savez("%s_state.npz" % name, iteration=iteration, seed=self.seed,
-                 accepted_count=accepted_count, sweep_origin=self.sweep_origin,
-                 keep_one_in=self.keep_one_in,
-                 total_accepted=accepted_count + self._acc_base,
-                 total_iterations=iteration + self._it_base,
-                 n_valid=(iteration - 1) // self.keep_one_in + 1,
-                 chain_file="" if self._chain_file is None else str(self._chain_file))
-        np.save("%s_parameters.npy" % name, self._host_chain.params if self._host_model
-                else self.engine.get_params())
+        cannot rewrite the file under the open mapping.
+        ``chains=R``: the parameter file holds the R maps, (R, H, W, P) -- what
+        `initial_parameters=` takes for R chains --, chain r > 0 goes to
+        `<name>_c<r>_chain.npy`, and the state records the chains' own accepted counts."""
         n_valid = (iteration - 1) // self.keep_one_in + 1
+        state = dict(iteration=iteration, seed=self.seed,
+                     accepted_count=accepted_count, sweep_origin=self.sweep_origin,
+                     keep_one_in=self.keep_one_in,
+                     total_accepted=accepted_count + self._acc_base,
+                     total_iterations=iteration + self._it_base,
+                     n_valid=n_valid, n_chains=self.n_chains,
+                     chain_file="" if self._chain_file is None else str(self._chain_file))
+        if self.n_chains > 1:
+            state["per_chain_accepted"] = np.array(
+                [a + b for a, b in zip(per_chain_accepted, self._acc_base_chain)], dtype=np.int64)
+        np.savez("%s_state.npz" % name, **state)
+        if self._host_model:
+            params = self._host_chain.params
+        elif self.n_chains == 1:
+            params = self.engine.get_params()
+        else:
+            params = np.stack([eng.get_params() for eng in self.engines])
+        np.save("%s_parameters.npy" % name, params)
         if self._chain_file is not None:
             # slots past n_valid (recorded in the state file) are not written yet
-            self.chain.flush()
-            self._likelihoods_map.flush()
+            for ch, lk in zip(self.chains, self._likelihoods_maps):
+                ch.flush()
+                lk.flush()
         else:
-            np.save("%s_chain.npy" % name, self.chain[:n_valid])
+            for r, ch in enumerate(self.chains):
+                prefix = name if r == 0 else "%s_c%d" % (name, r)
+                np.save("%s_chain.npy" % prefix, ch[:n_valid])
         self.logger.info("checkpoint at iteration %d (%d accepted) -> %s_*.npy"
                          % (iteration, accepted_count, name))
 

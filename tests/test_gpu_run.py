@@ -351,6 +351,35 @@ def test_run_chains_are_the_single_runs_of_their_seeds(batched, tmp_path):
         d3d.Run(cube, inst, seed=5, chains=2, initial_parameters=starts, **kw)
 
 
+def test_chains_checkpoint_and_resume(tmp_path):
+    """checkpoint= / resume_state= with chains=R: the checkpoint holds the R parameter maps
+    (what initial_parameters= takes for R chains), every chain's slots and accepted count;
+    6 + 6 sweeps of three chains equal their 12 sweeps in one go, acceptance rates included."""
+    inst, cube, var, _, _ = synthetic_cube(D=16, H=9, W=9, seed=4)
+    name = str(tmp_path / "ck")
+    kw = dict(variance=var, seed=3, chains=3, min_acceptance_rate=0., refresh_every=0)
+    whole = d3d.Run(cube, inst, max_iterations=13, **kw)
+    first = d3d.Run(cube, inst, max_iterations=7, write_every=7, checkpoint=name, **kw)
+    state = np.load(name + "_state.npz")
+    assert int(state["iteration"]) == 7 and int(state["n_chains"]) == 3
+    assert int(state["per_chain_accepted"].sum()) == int(state["total_accepted"])
+    saved = np.load(name + "_parameters.npy")
+    assert saved.shape == (3, 9, 9, 3)
+    for r in range(3):
+        np.testing.assert_array_equal(first.chains[r][-1], saved[r])
+        np.testing.assert_array_equal(
+            np.load(name + ("_chain.npy" if r == 0 else "_c%d_chain.npy" % r)), first.chains[r])
+    second = d3d.Run(cube, inst, max_iterations=7, initial_parameters=name + "_parameters.npy",
+                     resume_state=name + "_state.npz", **kw)
+    for r in range(3):
+        # (the resumed run rebuilds the residual from the parameters: rounding-level differences)
+        np.testing.assert_allclose(second.chains[r][-1], whole.chains[r][-1], rtol=1e-8, atol=1e-8)
+        assert abs(second.acceptance_rates[r] - whole.acceptance_rates[r]) < 1e-12
+    assert abs(second.acceptance_rate - whole.acceptance_rate) < 1e-12
+    with pytest.raises(ValueError, match="holds 3 chain"):
+        d3d.Run(cube, inst, max_iterations=3, resume_state=name + "_state.npz", variance=var)
+
+
 def test_run_initial_parameters_and_mask(tmp_path):
     """lib/run.py:294-307 (3-D, 1-D broadcast, .npy path) and masks: masked
     spaxels keep their parameters and contribute nothing (lib/run.py:553-566)."""

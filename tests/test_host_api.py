@@ -250,11 +250,15 @@ def test_run_rejects_bad_inputs_like_the_reference():
         d3d.Run(cube, inst, model=Inverted)
     with pytest.raises(ValueError, match="Initial params"): # lib/run.py:300-305
         d3d.Run(cube, inst, initial_parameters=np.zeros((3, 3, 3)))
-    # chains= (additive, like seed=): a positive integer; checkpoints take one chain
+    # chains= (additive, like seed=): a positive integer; a checkpoint resumes the number of
+    # chains it was written with
     with pytest.raises(AssertionError, match="chains"):
         d3d.Run(cube, inst, chains=0)
-    with pytest.raises(NotImplementedError, match="one chain"):
-        d3d.Run(cube, inst, chains=2, checkpoint="x")
+    one_chain_state = dict(iteration=3, seed=12345, accepted_count=5, sweep_origin=0)
+    with pytest.raises(ValueError, match="holds 1 chain"):
+        d3d.Run(cube, inst, chains=2, resume_state=one_chain_state)
+    with pytest.raises(ValueError, match="holds 4 chain"):
+        d3d.Run(cube, inst, resume_state=dict(one_chain_state, n_chains=4))
     with pytest.raises(ValueError, match="one map per chain"):
         d3d.Run(cube, inst, chains=2, initial_parameters=np.zeros((3, 9, 9, 3)))
 
