@@ -431,6 +431,8 @@ const OptDesc g_opts[] = {
     {"zmajor_hy", "D3D_ZMAJOR_HY", &d3d_ctx::zmajor_hy, OPT_LAUNCH, 1, 1 << 20},
     {"spectral_dense", "D3D_SPECTRAL_DENSE", &d3d_ctx::spectral_dense, OPT_LAUNCH, 0, 1},
     {"spectral_blocks", "D3D_SPECTRAL_BLOCKS", &d3d_ctx::spectral_blocks, OPT_LAUNCH, 0, 1},
+    {"lines_dense", "D3D_LINES_DENSE", &d3d_ctx::lines_dense, OPT_LAUNCH, 0, 3},
+    {"lines_rounds", "D3D_LINES_ROUNDS", &d3d_ctx::lines_rounds, OPT_LAUNCH, 0, 64},
     {"spatial_nt", "D3D_SPATIAL_NT", &d3d_ctx::sp_nt_opt, OPT_LAUNCH, 0, 1024},
     {"xcd_remap", "D3D_XCD_REMAP", &d3d_ctx::xcd_remap, OPT_LAUNCH, 0, 1},
     {"alt_dir", "D3D_ALT_DIR", &d3d_ctx::alt_dir, OPT_LAUNCH, 0, 1},

@@ -234,6 +234,11 @@ struct d3d_ctx {
     bool lsf_dense_ok = false;    // taps within +-LSF_RL and power-of-two depth (z-major spectral kernel)
     bool lsf_dense_any = false;   // taps within +-LSF_RL channels at ANY depth (k_spectral_blocks)
     int spectral_blocks = 1;      // option spectral_blocks = 0: never use k_spectral_blocks
+    int lines_dense = 1;          // option lines_dense: 0 the line cube by the tap-list kernel (k_lines); 1 by
+                                  // k_lines_dense where the LSF is applied with it (k_lines' bits); 2 always,
+                                  // with its own exp (within 2 ulp; measured 7-10 % faster: not the default);
+                                  // 3 always, with the library's exp (tests)
+    int lines_rounds = 0;         // option lines_rounds: spaxel rounds per wavefront of k_lines_dense (0: by size)
     bool lsf_fusable = false;     // taps within +-LSF_RL, power-of-two depth, strip within a wave
     int spectral_dense = 1;       // D3D_SPECTRAL_DENSE=0: always the general tap-list kernel
     int spectral_shfl = 0;        // D3D_SPECTRAL_SHFL=1: wavefront shuffles instead of the LDS window

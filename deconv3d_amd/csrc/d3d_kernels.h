@@ -237,6 +237,139 @@ __global__ __launch_bounds__(NT) void k_spectral_dense(int Dp, int HL, long nspa
     *reinterpret_cast<double2 *>(out + sp * Dp + 2 * zl) = acc;
 }
 
+// k_lines with the dense LSF (round 4): a group of HLG lanes of ONE wavefront (64 above 64
+// channels, else the power of two that holds the spectrum: 64 / HLG spaxels per wavefront)
+// builds its spaxel's line -- 2 HLG channels per step, `steps` steps -- into a wave-private LDS
+// buffer  ext[-LSF_RL, span + LSF_RL),  span = steps 2 HLG <= N:  the zero-extended,
+// N-periodic spectrum of convolve_1d's closed form (lib/convolution.py:89-160), whose two halos
+// are copies of line channels (the wrap of the padded grid) or zero.  Then every lane reads its
+// aligned window of 2 LSF_RL + 2 channels with 16-byte reads and applies the dense taps IN THE
+// ORDER OF THE TAP LIST (descending shift), so the cube equals k_lines' bit for bit.  No block
+// barrier, no index arithmetic per tap: 235 instead of 430 instructions per channel pair
+// (300x300x256: 114 -> 76 us).
+//
+// FAST (option lines_dense = 2, NOT the default): the line through a reciprocal and an own exp
+// for arguments <= 0 (13th-degree Taylor polynomial on |r| <= ln2 / 2 after Cody-Waite
+// reduction, ~ 45 instead of ~ 65 instructions per channel): within 2 ulp of unit_gaussian's
+// correctly divided, library exp.  Measured 7-10 % faster (300x300x128 without the LSF 33.5
+// against 35.9 us, x256 with it 68 against 76): the kernel is bound by the dependent fp64
+// chain of the exp, not by its instruction count (without its stores 27.7 against 30.3 us;
+// without the exp, stores only, 23; neither 13) -- not worth a line cube that differs from
+// the sweep kernels' unit_gaussian in the last bits.
+__device__ __forceinline__ double exp_nonpositive(double x) {
+    x = x < -800.0 ? -800.0 : x;  // (e^-800 is zero in fp64; NaN stays NaN)
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;   // 1 / 13!
+    p = fma(p, r, 2.08767569878681e-09);     // 1 / 12!
+    p = fma(p, r, 2.505210838544172e-08);    // 1 / 11!
+    p = fma(p, r, 2.755731922398589e-07);    // 1 / 10!
+    p = fma(p, r, 2.7557319223985893e-06);   // 1 / 9!
+    p = fma(p, r, 2.48015873015873e-05);     // 1 / 8!
+    p = fma(p, r, 1.984126984126984e-04);    // 1 / 7!
+    p = fma(p, r, 1.388888888888889e-03);    // 1 / 6!
+    p = fma(p, r, 8.333333333333333e-03);    // 1 / 5!
+    p = fma(p, r, 4.1666666666666664e-02);   // 1 / 4!
+    p = fma(p, r, 1.6666666666666666e-01);   // 1 / 3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)k);
+}
+
+template <bool FAST>
+static __global__ __launch_bounds__(256) void k_lines_dense(SpectralArgs A, int HLG, int steps, int L,
+                                                            const double *__restrict__ wl,
+                                                            const double *__restrict__ params,
+                                                            const uint8_t *__restrict__ mask,
+                                                            double *__restrict__ out, int convolved) {
+    extern __shared__ double smem[];
+    constexpr int RL = LSF_RL;
+    const int S = 64 / HLG;  // spaxels per wavefront and round
+    const int lane = threadIdx.x & 63;
+    const int g = lane / HLG, zl = lane - g * HLG;
+    // a wavefront takes L rounds of S consecutive spaxels, S L <= 64 (a wavefront per spaxel
+    // lives for one memory round trip and ~ 150 instructions: that launch is bound by the
+    // latency of its parameter loads at the occupancy it has).  Lane j loads the parameters of
+    // spaxel j of the wavefront ONCE; the rounds take them by shuffle, so nothing waits on
+    // memory between the stores of one round and the channels of the next.
+    const long spbase = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * S * L;
+    const int span = steps * 2 * HLG;
+    double *buf = smem + (size_t)((threadIdx.x >> 6) * S + g) * (span + 2 * RL) + RL;  // -> channel 0
+    const bool use_lsf = convolved && A.ntaps > 0;
+    double t[2 * RL + 1];
+    if (use_lsf) {
+#pragma unroll
+        for (int j = 0; j < 2 * RL + 1; ++j) t[j] = wl[j];
+    }
+    double pa = 0, pc = 0, pw = 1;
+    int plive = 0;
+    if (lane < S * L && spbase + lane < A.nspax) {
+        plive = mask[spbase + lane] != 0;
+        pa = params[(spbase + lane) * 3 + 0];
+        pc = params[(spbase + lane) * 3 + 1];
+        pw = params[(spbase + lane) * 3 + 2];
+    }
+    for (int it = 0; it < L; ++it) {
+        if (spbase + (long)it * S >= A.nspax) break;  // (wave-uniform)
+        const int src = it * S + g;
+        const long sp = spbase + src;
+        const bool active = sp < A.nspax;
+        const double a = __shfl(pa, src), c = __shfl(pc, src), w = __shfl(pw, src);
+        const bool live = __shfl(plive, src) != 0;
+        const double inv_w2 = 1.0 / (2.0 * w * w);  // (FAST; w == 0 or a denormal 2 w^2: the delta at z == c)
+        auto line_at = [&](int zi) {
+            if (!FAST) return a * unit_gaussian((double)zi, c, w);
+            const double d = (double)zi - c;
+            return inv_w2 <= 1.79769313486231570815e+308 ? a * exp_nonpositive(-(d * d) * inv_w2)
+                                                         : (d == 0.0 ? a : a * 0.0);
+        };
+        for (int b = 0; b < steps; ++b) {
+            const int z = b * 2 * HLG + 2 * zl;
+            double2 v = make_double2(0.0, 0.0);
+            if (live) {
+                v.x = (z < A.D) ? line_at(z) : 0.0;
+                v.y = (z + 1 < A.D) ? line_at(z + 1) : 0.0;
+            }
+            if (use_lsf) *reinterpret_cast<double2 *>(buf + z) = v;
+            else if (active && z < A.Dp) *reinterpret_cast<double2 *>(out + sp * A.Dp + z) = v;
+        }
+        if (!use_lsf) continue;
+        __builtin_amdgcn_wave_barrier();  // wave-private buffer: LDS is in order per wave
+        if (zl < RL) {  // the halos: pairs at m = -RL + 2 zl (front), span + 2 (zl - RL / 2) (back)
+            const int m = zl < RL / 2 ? -RL + 2 * zl : span + 2 * (zl - RL / 2);
+            int idx = m % A.N;
+            if (idx < 0) idx += A.N;
+            // (idx even: idx < D leaves idx + 1 <= span - 1, a channel the steps above wrote)
+            const double2 h = idx < A.D ? *reinterpret_cast<const double2 *>(buf + idx) : make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(buf + m) = h;
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int b = 0; b < steps; ++b) {
+            const int z = b * 2 * HLG + 2 * zl;
+            if (z >= A.Dp) break;
+            double win[2 * RL + 2];
+#pragma unroll
+            for (int j = 0; j < RL + 1; ++j) {
+                const double2 p = *reinterpret_cast<const double2 *>(buf + z - RL + 2 * j);
+                win[2 * j] = p.x;
+                win[2 * j + 1] = p.y;
+            }
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 2 * RL; j >= 0; --j) {
+                acc.x = fma(t[j], win[j], acc.x);
+                acc.y = fma(t[j], win[j + 1], acc.y);
+            }
+            if (!live || z >= A.D) acc.x = 0.0;
+            if (!live || z + 1 >= A.D) acc.y = 0.0;
+            if (active) *reinterpret_cast<double2 *>(out + sp * A.Dp + z) = acc;
+        }
+        __builtin_amdgcn_wave_barrier();  // (the next round rewrites the buffer)
+    }
+}
+
 // The dense form for ANY depth (round 3): a wavefront takes one 128-channel BLOCK of one
 // spectrum, [z0, z0 + 128), and the LSF_RL channels either side of it,
 //   out[k] = sum_j wl[j] * ext[(k + j - LSF_RL) mod N],  ext = the spectrum zero-extended to N

@@ -41,6 +41,37 @@ int launch_lines_nt(d3d_ctx *c, double *out, int convolved, const double *params
 // params: (H,W,3) map on the device (NULL: the chain state c->params)
 int launch_lines(d3d_ctx *c, double *out, int convolved, const double *params) {
     if (!params) params = c->params;
+    // the LSF applied here (depths whose FSF pass has no LSF epilogue) and its taps within +-8
+    // channels: a lane group of one wavefront per spaxel, dense taps, no block barrier --
+    // 300x300x256: 114 -> 76 us.  Without the LSF the kernel is bound by the fp64 instructions of
+    // its two exp per thread either way (35.2 against 35.9 us at 128 channels, 24.4 against 25.2
+    // at 64: profiles/r04_line_kernels.txt) and the tap-list kernel stays.
+    const bool use_lsf = convolved && c->ntaps > 0;
+    if (!c->deep && ((c->lines_dense == 1 && use_lsf && c->lsf_dense_any) ||
+                     (c->lines_dense >= 2 && (!use_lsf || c->lsf_dense_any)))) {
+        int hlg = 8;
+        while (hlg < 64 && 2 * hlg < c->Dp) hlg *= 2;
+        const int steps = (c->Dp + 2 * hlg - 1) / (2 * hlg), S = 64 / hlg;
+        const size_t lds = (size_t)4 * S * (steps * 2 * hlg + 2 * d3d::LSF_RL) * sizeof(double);
+        if (lds <= 64 * 1024) {
+            // rounds per wavefront: up to 8 while the launch keeps >= 4096 wavefronts
+            int L = (int)std::min<long>(8, std::max<long>(1, c->HW / ((long)S * 4096)));
+            if (c->lines_rounds > 0) L = std::min(c->lines_rounds, 64 / S);  // (a lane per spaxel of the wavefront)
+            const unsigned grid = (unsigned)((c->HW + (long)4 * S * L - 1) / ((long)4 * S * L));
+            if (c->lines_dense == 2)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_lines_dense<true>), dim3(grid), dim3(256),
+                                   use_lsf ? lds : 0, c->stream, spectral_args(c), hlg, steps, L,
+                                   (const double *)c->lsf_dense, params, (const uint8_t *)c->mask, out,
+                                   convolved);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_lines_dense<false>), dim3(grid), dim3(256),
+                                   use_lsf ? lds : 0, c->stream, spectral_args(c), hlg, steps, L,
+                                   (const double *)c->lsf_dense, params, (const uint8_t *)c->mask, out,
+                                   convolved);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
+    }
     if (c->deep) {
         d3d::SpectralArgs A = spectral_args(c);
         const size_t lds = (size_t)c->N * sizeof(double);

@@ -78,8 +78,8 @@ class Run:
     per-parameter Gelman-Rubin map, ``run.acceptance_rates`` the per-chain rates; the stopping
     rule looks at the pooled acceptance rate.  ``initial_parameters`` may be 4-D, one map per
     chain; a checkpoint holds all R chains (``<prefix>_parameters.npy`` is that 4-D array, chain
-    r > 0's slots are ``<prefix>_c<r>_chain.npy``) and resumes R chains.  Custom (host-evaluated)
-    line models take one chain.
+    r > 0's slots are ``<prefix>_c<r>_chain.npy``) and resumes R chains.  A custom
+    (host-evaluated) line model advances its R chains one after the other.
     """
 
     def __init__(
@@ -301,10 +301,6 @@ class Run:
                 resumed_per_chain = [int(v) for v in state["per_chain_accepted"]]
 
         # ---- device context ----------------------------------------------
-        if self._host_model and n_chains > 1:
-            raise NotImplementedError("chains= needs a line model evaluated on the device "
-                                      "(SingleGaussianLineModel); %s runs on the host"
-                                      % type(self.model).__name__)
         self.engines = []
         for r in range(n_chains):
             eng = _lib.Engine(cube_shape, self.fsf.shape, device=device)
@@ -317,10 +313,12 @@ class Run:
             from .host_model import HostModelChain
             self.logger.info("Line model %s is evaluated on the host (slower path)."
                              % type(self.model).__name__)
-            host_chain = HostModelChain(self, self.engine, self.chain[0], min_boundaries,
-                                        max_boundaries, jumping_amplitude, gibbs_apriori_variance,
-                                        self.seed, refresh_every)
-            self._host_chain = host_chain
+            # (chains=R: one host chain per engine, seeds seed + r, advanced one after the other)
+            self._host_chains = [
+                HostModelChain(self, self.engines[r], self.chains[r][0], min_boundaries,
+                               max_boundaries, jumping_amplitude, gibbs_apriori_variance,
+                               self.seed + r, refresh_every) for r in range(n_chains)]
+            host_chain = self._host_chain = self._host_chains[0]
         else:
             for r, eng in enumerate(self.engines):
                 eng.set_params(self.chains[r][0])
@@ -332,7 +330,8 @@ class Run:
                 for eng in self.engines:
                     eng.set_sweep_origin(self.sweep_origin)
             else:
-                host_chain.set_sweep_origin(self.sweep_origin)
+                for hc in self._host_chains:
+                    hc.set_sweep_origin(self.sweep_origin)
         self.logger.info("Iteration #1")
         if host_chain is None:
             for eng in self.engines:
@@ -376,10 +375,13 @@ class Run:
             if host_chain is not None:
                 save = cur_iteration % keep_one_in == 0
                 slot = cur_iteration // keep_one_in
-                accepted_count += host_chain.sweep(cur_iteration,
-                                                   likelihoods[slot] if save else None)
+                acc = [hc.sweep(cur_iteration, all_likelihoods[r][slot] if save else None)
+                       for r, hc in enumerate(self._host_chains)]
+                accepted_count += sum(acc)
+                per_chain_accepted = [a + b for a, b in zip(per_chain_accepted, acc)]
                 if save:
-                    self.chain[slot] = host_chain.params
+                    for r, hc in enumerate(self._host_chains):
+                        self.chains[r][slot] = hc.params
             elif n_chains == 1:
                 t_call = _time.perf_counter()
                 accepted_count += self.engine.mh_sweeps(n, cur_iteration, keep_one_in,
@@ -500,11 +502,10 @@ class Run:
                 [a + b for a, b in zip(per_chain_accepted, self._acc_base_chain)], dtype=np.int64)
         np.savez("%s_state.npz" % name, **state)
         if self._host_model:
-            params = self._host_chain.params
-        elif self.n_chains == 1:
-            params = self.engine.get_params()
+            maps = [hc.params for hc in self._host_chains]
         else:
-            params = np.stack([eng.get_params() for eng in self.engines])
+            maps = [eng.get_params() for eng in self.engines]
+        params = maps[0] if self.n_chains == 1 else np.stack(maps)
         np.save("%s_parameters.npy" % name, params)
         if self._chain_file is not None:
             # slots past n_valid (recorded in the state file) are not written yet

@@ -175,6 +175,25 @@ def test_run_with_custom_line_model(model_cls):
     assert 0 < run.acceptance_rate <= 1
 
 
+def test_custom_line_model_with_several_chains():
+    """chains=R with a host-evaluated model: chain r is the chain of Run(..., seed=seed + r)."""
+    D, H, W = 32, 8, 8
+    inst = d3d.MUSE(fsf_fwhm=0.5)
+    rng = np.random.default_rng(1)
+    truth = np.dstack((3 + 3 * rng.random((H, W)), 10 + 10 * rng.random((H, W)), 1 + rng.random((H, W))))
+    cube, var = _cube_from(LorentzLineModel(), truth, inst, D, H, W, seed=2)
+    kw = dict(variance=var, model=LorentzLineModel, max_iterations=9, keep_one_in=2, jump_amplitude=0.3,
+              initial_parameters=truth * 1.15)
+    multi = d3d.Run(cube, inst, seed=5, chains=2, **kw)
+    assert multi._host_model and multi.rhat.shape == (H, W, 3)
+    for r in range(2):
+        one = d3d.Run(cube, inst, seed=5 + r, **kw)
+        np.testing.assert_array_equal(multi.chains[r], one.chain)
+        np.testing.assert_array_equal(multi.all_likelihoods[r][1:], one.likelihoods[1:])
+        assert multi.acceptance_rates[r] == one.acceptance_rate
+    assert not np.array_equal(multi.chains[0][-1], multi.chains[1][-1])
+
+
 def test_gaussian_subclass_with_own_bounds_stays_on_device():
     class Narrow(d3d.SingleGaussianLineModel):
         def max_boundaries(self, runner):
