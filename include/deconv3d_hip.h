@@ -94,7 +94,7 @@ int d3d_timer_stop(d3d_ctx *ctx, double *elapsed_ms);
  * Keys: mh_defer 0|1|2, mh_zblocks, mh_layers 0(auto)|1|2|3,
  * mh_wide, mh_props, halo_timing, mh_zigzag, mh_nt_ivar -1(auto)|0|1, mh_nt, uniform_ivar, conv_rows,
  * conv_zb, conv_hy, spatial_sep, sep_fuse, spatial_mode, march_hy, zmajor, zmajor_hy,
- * spectral_dense, spectral_blocks, spatial_nt, xcd_remap, alt_dir, stagger; a build with
+ * spectral_dense, spectral_blocks, lines_dense, lines_rounds, spatial_nt, xcd_remap, alt_dir, stagger; a build with
  * `make EXPERIMENTS=1` adds mh_chain, mh_prio, mh_maxit, mh_flow, mh_pair, spectral_shfl, fuse_lsf, march_pf,
  * march_one, march_stamp.  Unknown key or value out of range: D3D_ERR_INVALID.
  * d3d_ctx_get_option also answers the read-only key "chain_parts": how many of the
