@@ -428,7 +428,7 @@ const OptDesc g_opts[] = {
     {"spatial_mode", "D3D_SPATIAL_MODE", &d3d_ctx::march_mode, OPT_LAUNCH, 0, 3},
     {"march_hy", "D3D_MARCH_HY", &d3d_ctx::march_hy_opt, OPT_TAPS, 0, 1 << 20},
     {"zmajor", "D3D_ZMAJOR", &d3d_ctx::zmajor, OPT_LAUNCH, 0, 1},
-    {"zmajor_hy", "D3D_ZMAJOR_HY", &d3d_ctx::zmajor_hy, OPT_LAUNCH, 1, 1 << 20},
+    {"zmajor_hy", "D3D_ZMAJOR_HY", &d3d_ctx::zmajor_hy, OPT_LAUNCH, 0, 1 << 20},
     {"spectral_dense", "D3D_SPECTRAL_DENSE", &d3d_ctx::spectral_dense, OPT_LAUNCH, 0, 1},
     {"spectral_blocks", "D3D_SPECTRAL_BLOCKS", &d3d_ctx::spectral_blocks, OPT_LAUNCH, 0, 1},
     {"lines_dense", "D3D_LINES_DENSE", &d3d_ctx::lines_dense, OPT_LAUNCH, 0, 3},

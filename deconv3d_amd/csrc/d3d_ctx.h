@@ -247,7 +247,7 @@ struct d3d_ctx {
     int march_hy_opt = 0;         // option march_hy (0: chosen per shape)
     int conv_hy_opt = 0;          // option conv_hy: rows per strip of k_conv_rows (0: one strip per CU)
     int zmajor = 1;               // option zmajor = 0: d3d_convolve never uses the reference-layout kernels
-    int zmajor_hy = 32;           // output rows per strip of the z-major spatial kernel
+    int zmajor_hy = 0;            // output rows per strip of the z-major spatial kernel (0: by shape)
     int sp_nt_opt = 0;            // option spatial_nt: workgroup size of the spatial kernels (0: by depth)
     int xcd_remap = 1, alt_dir = 1, stagger = 0;  // march kernels: workgroup -> XCD mapping, strip direction
     // host copies of the taps, so that an option that changes their analysis can redo it

@@ -594,7 +594,17 @@ bool zmajor_ok(const d3d_ctx *c) {
 
 template <int FS>
 int launch_spatial_z(d3d_ctx *c, const double *in, double *out) {
-    const int HY = c->zmajor_hy;
+    // rows per strip (option zmajor_hy; 0 = by shape).  A wavefront's march is a dependent chain
+    // of HY + FS - 1 steps of ~ 0.75 us whatever else runs, so: the shortest strips whose
+    // wavefronts are all resident at once (4 per SIMD: 4096), at least 4 rows --
+    // 300x300x128: 50 rows, 116 against 134 us per convolution at 32; 64^3: 4 rows, 28.5 against
+    // 40.7; 300x300x256: 100 rows, 290 against 317 (tools/zmajor_time.py).
+    int HY = c->zmajor_hy;
+    if (HY <= 0) {
+        const long per_row_of_strips = (long)c->D * ((c->W + 63) / 64);
+        const long nys = std::max<long>(1, 4096 / per_row_of_strips);
+        HY = (int)std::max<long>(4, (c->H + nys - 1) / nys);
+    }
     const long items = (long)c->D * ((c->H + HY - 1) / HY) * ((c->W + 63) / 64);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(d3d::k_spatial_z<FS>), dim3((unsigned)((items + 3) / 4)),
                        dim3(256), 0, c->stream, c->D, c->H, c->W, HY, (const double *)c->fsf, in,
