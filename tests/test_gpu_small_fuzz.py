@@ -90,3 +90,49 @@ def test_random_small_launch_problem_is_bit_identical_to_round3s_kernels(seed):
     assert on_small > 0 and on_old == 0        # (the launches under test did take k_mh_small)
     for a, b in zip(new, old):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("D3D_TEST_RANDOM_BATCH", "12"))))
+def test_random_batched_chains_are_the_chains_they_would_be_alone(seed):
+    """d3d_mh_sweeps_batch on the same random problems (unpartitioned): R chains of one geometry --
+    own data, start and seed each -- advanced by ONE launch per colour class are, bit for bit,
+    the chains their contexts produce alone (k_mh_small<..., BATCH> while the joint launch does
+    not fill the chip, k_mh_ws's batched form once it does), over two calls."""
+    from deconv3d_amd import ensemble
+    c = draw(seed)
+    rng = np.random.default_rng(9000 + seed)
+    R = int(rng.integers(2, 9))
+    shape = (c["D"], c["H"], c["W"])
+    mn, mx = np.array([0.0, 0.0, 0.3]), np.array([30.0, c["D"] - 1.0, 6.0])
+
+    def make(r):
+        eng = _lib.Engine(shape, c["fsf"].shape, options=c["opts"])
+        eng.set_taps(c["fsf"], c["lsf"])
+        data = c["data"] * (1.0 + 0.1 * r)
+        if c["uniform"]:
+            eng.set_data(data, None, var_scalar=float(c["var"].flat[0]) * (1.0 + 0.2 * r), mask=c["mask"])
+        else:
+            eng.set_data(data, c["var"] * (1.0 + 0.05 * r), mask=c["mask"])
+        init = c["init"].copy()
+        init[..., 2] = np.clip(init[..., 2] + 0.05 * r, 0.3, 6.0)
+        eng.set_params(init)
+        eng.mh_config(mn, mx, 0.1, 900.0, seed=c["seed"] + r, refresh_every=c["refresh"])
+        return eng
+
+    alone = []
+    for r in range(R):
+        with make(r) as eng:
+            acc = eng.mh_sweeps(c["sweeps"], 1) + eng.mh_sweeps(2, c["sweeps"] + 1)
+            alone.append((eng.get_params(), eng.download_slot(_lib.SLOT_ERR), eng.get_dlog(), acc))
+    engs = [make(r) for r in range(R)]
+    try:
+        a1 = ensemble.sweep_chains_batched(engs, c["sweeps"], 1)
+        a2 = ensemble.sweep_chains_batched(engs, 2, c["sweeps"] + 1)
+        for r, eng in enumerate(engs):
+            np.testing.assert_array_equal(eng.get_params(), alone[r][0])
+            np.testing.assert_array_equal(eng.download_slot(_lib.SLOT_ERR), alone[r][1])
+            np.testing.assert_array_equal(eng.get_dlog(), alone[r][2])
+            assert a1[r] + a2[r] == alone[r][3]
+    finally:
+        for e in engs:
+            e.close()
