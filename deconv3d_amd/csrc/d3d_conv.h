@@ -252,7 +252,12 @@ __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, in
                                                                  wave, lane, rows, myspec, q, w, data,
                                                                  out, ring, dnext);
             // keep the steps apart: interleaving two of them costs more registers than the
-            // 128 that four wavefronts per SIMD allow
+            // 128 that four wavefronts per SIMD allow.  (Round 4: requesting the NEXT row's FS
+            // values right after this row's fold -- the workgroup's wavefronts leave the
+            // row-pair barrier together, wait on the LDS together, compute together: half their
+            // resident cycles are parked on s_waitcnt, profiles/r04_issue_counters.txt -- needs
+            // 44 more registers across the dot products: 128 VGPRs and 167-467 spills in every
+            // instantiation.  Not kept.)
             __builtin_amdgcn_sched_barrier(0);
         }
         conv_rows_steps<FS, NW, LSF, RESID, SEP, DPS, ZB, PH + 1>(base, nsteps, y0, yend, rowstride, cstride,
