@@ -257,7 +257,9 @@ __device__ __forceinline__ void conv_rows_steps(int base, int nsteps, int y0, in
             // row-pair barrier together, wait on the LDS together, compute together: half their
             // resident cycles are parked on s_waitcnt, profiles/r04_issue_counters.txt -- needs
             // 44 more registers across the dot products: 128 VGPRs and 167-467 spills in every
-            // instantiation.  Not kept.)
+            // instantiation.  Not kept.  Nor were the FHH + 1 dot products advancing together, tap
+            // column by tap column (six independent chains, the centre column's products issued
+            // while the outer columns are still on their way): 116 VGPRs, 62.8 against 54.4 us.)
             __builtin_amdgcn_sched_barrier(0);
         }
         conv_rows_steps<FS, NW, LSF, RESID, SEP, DPS, ZB, PH + 1>(base, nsteps, y0, yend, rowstride, cstride,
