@@ -1483,8 +1483,11 @@ static __global__ __launch_bounds__(256) void k_spectral_z(int D, long HW, const
 // (y symmetry).  The ring (FS doubles per thread) rotates at compile time.  An
 // input value is loaded once per tile (plus the halo), the kernel needs ~60
 // VGPRs: 8 wavefronts per SIMD, HBM-bound.
+// (Asked for six wavefronts per SIMD the compiler needs 68 instead of 122 VGPRs at FS = 11 without a
+// spill -- 9 and 15 taps spill there and keep four: 300x300x128 109 -> 100 us per convolution,
+// 64^3 25 -> 21.)
 template <int FS>
-__global__ __launch_bounds__(256) void k_spatial_z(int D, int H, int W, int HY,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((FS == 9 || FS == 15) ? 4 : 6, 8))) void k_spatial_z(int D, int H, int W, int HY,
                                                    const double *__restrict__ fsf,
                                                    const double *__restrict__ in,
                                                    double *__restrict__ out) {
